@@ -1,0 +1,158 @@
+/*
+ * libmgx — C-ABI of the MI355X (gfx950) kernels behind the progressive-GAN training step of
+ * yefeza/music-generator (trainer/models.py, driven by trainer/task.py).
+ *
+ * The reference has no FFI of its own: its arithmetic is delegated to TensorFlow/Keras layer
+ * objects.  Each entry point below therefore replaces the TensorFlow kernel(s) behind one Keras
+ * layer / TF op that trainer/models.py instantiates, and cites that call site.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer owned by the caller (row-major NHWC float32 unless said
+ *     otherwise); nothing is allocated, freed or synchronised inside the library;
+ *   - `stream` is a hipStream_t passed as void*; all work is enqueued on it and the call returns;
+ *   - return value: 0 = ok (MGX_OK), 1 = bad argument, 2 = launch failure, 3 = workspace too small;
+ *   - calls are stateless and re-entrant per stream; results are bitwise reproducible (no float
+ *     atomics: every cross-workgroup sum is a fixed-order two-stage reduction through a
+ *     caller-provided workspace).
+ */
+#ifndef MGX_H
+#define MGX_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+#define MGX_OK 0
+#define MGX_ERR_ARG 1
+#define MGX_ERR_LAUNCH 2
+#define MGX_ERR_WORKSPACE 3
+
+int mgx_version(void);
+
+/* ------------------------------------------------------------------------------------------
+ * Contractions: one implicit-GEMM descriptor covers Conv2D ('same' stride 1, 'valid' strided),
+ * Conv2DTranspose with kernel == stride, Dense on the last axis, and the data-gradient of each.
+ *
+ *   rows    r = (img, ho, wo)  over nimg*hout*wout
+ *   columns n = (a', b', co)   over ngemm = dkh*dkw*cout          (depth-to-space on store)
+ *   acc[r][n] = sum_{a<kh, b<kw, k<cin} X[img, ho*sh+a-pt, wo*sw+b-pl, k] * W[tap(a,b)][k][n]
+ *               (out-of-range input positions contribute 0; if xmul != NULL, X is multiplied
+ *                element-wise by xmul on load: used for dY (.) f'(pre-activation))
+ *   v = acc + bias[n % nbias];  if act_alpha > 0: v' = tanh(v) + v/act_alpha, and
+ *       dact (if != NULL) receives 1 - tanh(v)^2 + 1/act_alpha
+ *   Y[img, ho*dkh+a', wo*dkw+b', co] (+)= v'
+ *   W[tap][k][n] is read at  w + tap*wtap + k*wsk + n*wsn  with one of wsk, wsn equal to 1;
+ *   flip = 1 uses tap (kh-1-a, kw-1-b) for gather position (a,b) (data-gradient of a conv).
+ * ------------------------------------------------------------------------------------------ */
+typedef struct {
+    int32_t nimg, hin, win, cin;
+    int32_t hout, wout;
+    int32_t kh, kw, sh, sw, pt, pl;
+    int32_t flip;
+    int32_t ngemm;
+    int32_t dkh, dkw, cout;
+    int32_t wsk, wsn;
+    int64_t wtap;
+    int32_t nbias;
+    int32_t accumulate;
+    float act_alpha;
+} mgx_conv_desc;
+
+/* Forward / data-gradient implicit GEMM on v_mfma_f32_32x32x2_f32.
+ * Replaces the TF kernels behind Conv2D (models.py:256-281, 314-335, 363, 416), Conv2DTranspose
+ * (models.py:365-393, 418-444), Dense on rank-4 tensors (models.py:366-399, 419-450), the
+ * SoftRectifier that follows every discriminator conv (models.py:205-206, fused as epilogue), and
+ * their tf.GradientTape data-gradients (models.py:118, 144). */
+int mgx_conv_gemm_f32(const mgx_conv_desc* d, const float* x, const float* xmul, const float* w,
+                      const float* bias, float* y, float* dact, void* stream);
+
+/* Weight/bias gradient of the same contraction (tf.GradientTape, models.py:118, 144):
+ *   dW[tap][k][n] += sum_r X[gather(r, tap)][k] * dY[scatter(r, n)]   (dY multiplied by dymul if set)
+ *   dB[n % nbias] += sum_r dY[scatter(r, n)]
+ * `workspace` holds per-split partial tiles; its size in bytes comes from
+ * mgx_conv_wgrad_workspace().  Fixed-order reduction: bitwise reproducible. */
+int64_t mgx_conv_wgrad_workspace(const mgx_conv_desc* d);
+int mgx_conv_wgrad_f32(const mgx_conv_desc* d, const float* x, const float* dy, const float* dymul,
+                       float* dw, float* dbias, void* workspace, int64_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------
+ * Non-contraction layers (HBM-bound, coalesced, wavefront reductions)
+ * ------------------------------------------------------------------------------------------ */
+
+/* UpSampling2D() nearest x2 (models.py:362) and its gradient (sum of the 2x2 block). */
+int mgx_upsample2x_fwd(const float* x, float* y, int64_t nimg, int h, int w, int c, void* stream);
+int mgx_upsample2x_bwd(const float* dy, float* dx, int64_t nimg, int h, int w, int c, int accumulate, void* stream);
+
+/* AveragePooling2D() 2x2/2 (models.py:292) and its gradient; h, w are the INPUT sizes. */
+int mgx_avgpool2x_fwd(const float* x, float* y, int64_t nimg, int h, int w, int c, void* stream);
+int mgx_avgpool2x_bwd(const float* dy, float* dx, int64_t nimg, int h, int w, int c, int accumulate, void* stream);
+
+/* keras Add of up to 8 tensors (models.py:395, 446). */
+int mgx_add_n(const float* const* xs, int nin, float* y, int64_t n, void* stream);
+/* dst += src (gradient fan-in). */
+int mgx_add_inplace(float* dst, const float* src, int64_t n, void* stream);
+
+/* WeightedSum (models.py:30-35): y = (1-alpha)*a + alpha*b, alpha read from device memory.
+ * Backward: da (+)= (1-alpha)*dy, db (+)= alpha*dy, dalpha += sum(dy*(b-a)) (if dalpha != NULL;
+ * workspace of mgx_reduce_workspace() bytes). da/db may be NULL. */
+int mgx_weighted_sum_fwd(const float* a, const float* b, const float* alpha, float* y, int64_t n, void* stream);
+int mgx_weighted_sum_bwd(const float* dy, const float* a, const float* b, const float* alpha,
+                         float* da, int acc_a, float* db, int acc_b, float* dalpha,
+                         void* workspace, int64_t workspace_bytes, int64_t n, void* stream);
+int64_t mgx_reduce_workspace(void);
+
+/* LayerNormalization(axis=[1,2,3]) (models.py:400, 405, 451): per-sample mean / biased variance
+ * over e = H*W*C elements, epsilon eps, gamma/beta of e elements.  stats receives (mean, rstd)
+ * per sample (2*nimg floats).  Backward: dx (+)=..., dgamma += , dbeta += (sums over the batch). */
+int64_t mgx_layernorm_workspace(int64_t nimg, int64_t e);
+int mgx_layernorm_fwd(const float* x, const float* gamma, const float* beta, float* y, float* stats,
+                      int64_t nimg, int64_t e, float eps, void* workspace, int64_t workspace_bytes, void* stream);
+int mgx_layernorm_bwd(const float* dy, const float* x, const float* gamma, const float* stats,
+                      float* dx, int acc_x, float* dgamma, float* dbeta,
+                      int64_t nimg, int64_t e, void* workspace, int64_t workspace_bytes, void* stream);
+
+/* MinibatchStdDev (models.py:167-192): x (n,h,w,c) -> y (n,h+1,w,c); group g = min(4,n), sample i
+ * belongs to group i % (n/g); the group statistic fills row h.  stat receives n/g floats.
+ * Backward: dx = dy[:, :h] + d(stat)/dx * sum(dy[:, h]). */
+int64_t mgx_mbstd_workspace(int64_t n, int64_t e);
+int mgx_mbstd_fwd(const float* x, float* y, float* stat, int64_t n, int h, int w, int c,
+                  void* workspace, int64_t workspace_bytes, void* stream);
+int mgx_mbstd_bwd(const float* dy, const float* x, float* dx, int64_t n, int h, int w, int c,
+                  void* workspace, int64_t workspace_bytes, void* stream);
+
+/* SoftRectifier / StaticOptTanh stand-alone (models.py:205-206, 219-220): y = tanh(x) + x/alpha;
+ * backward dx (+)= dy * (1 - tanh(x)^2 + 1/alpha). */
+int mgx_softrect_fwd(const float* x, float* y, int64_t n, float alpha, void* stream);
+int mgx_softrect_bwd(const float* dy, const float* x, float* dx, int accumulate, int64_t n, float alpha, void* stream);
+
+/* Flatten + Dense(1) (models.py:339-340): y[i] = sum_e x[i,e]*w[e] + b.  Backward: dx[i,e] =
+ * dy[i]*w[e] (if dx != NULL), dw[e] += sum_i dy[i]*x[i,e], db += sum_i dy[i] (if dw != NULL). */
+int mgx_dense1_fwd(const float* x, const float* w, const float* b, float* y, int64_t n, int64_t e, void* stream);
+int mgx_dense1_bwd(const float* dy, const float* x, const float* w, float* dx, float* dw, float* db,
+                   int64_t n, int64_t e, void* stream);
+
+/* Losses (models.py:468-484) and the 6 metrics (models.py:128-130, 154-156).
+ * mgx_logit_sums: sums[0] = sum(fake), sums[1] = sum(real) over n local logits (the pair that a
+ *   data-parallel run all-reduces).
+ * mgx_wgan_loss: from the GLOBAL sums and global batch n_global: ci, cu, sign = (cu-ci)/|cu-ci|
+ *   (0 if equal); mode 0 = discriminator_loss, 1 = generator_loss; out[0]=loss, out[1]=cu,
+ *   out[2]=ci, out[3]=|cu-ci|; dfake/dreal (n_local each, may be NULL) receive dloss/dlogit:
+ *   mode 0: dreal = (sign+1e-4)/n_global, dfake = -(sign+9.99e-5)/n_global;
+ *   mode 1: dfake = sign/n_global (sign treated as a constant). */
+int mgx_logit_sums(const float* fake, const float* real, int64_t n, float* sums, void* stream);
+int mgx_wgan_loss(const float* sums, int64_t n_global, int mode, float* out4,
+                  float* dfake, float* dreal, int64_t n_local, void* stream);
+
+/* Adam.apply_gradients with the hyper-parameters of models.py:502-503 (beta_1 = 0 so m == g):
+ *   v = beta2*v + (1-beta2)*g*g;  p -= lr_t * g / (sqrt(v) + eps).
+ * Multi-tensor: tensor i has n[i] elements at p[i], its gradient and second moment at offset
+ * off[i] of the flat buffers g and v.  The three tables live in device memory; blk_tensor /
+ * blk_start (nblocks entries, device) map each 1024-thread-block's chunk of 4096 elements. */
+int mgx_adam_multi(float* const* p, const int64_t* n, const int64_t* off, const float* g, float* v,
+                   const int32_t* blk_tensor, const int64_t* blk_start, int64_t nblocks,
+                   float lr_t, float beta2, float eps, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

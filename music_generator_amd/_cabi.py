@@ -1,0 +1,99 @@
+"""ctypes binding of libmgx.so (the C-ABI declared in include/mgx.h).
+
+There is no fallback: if the shared library is missing or a call returns a non-zero status the
+caller gets an exception.  Nothing here computes; it only marshals device pointers and sizes.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libmgx.so")
+
+MGX_OK = 0
+_ERR = {1: "bad argument", 2: "kernel launch failure", 3: "workspace too small"}
+
+
+class MgxError(RuntimeError):
+    pass
+
+
+class ConvDesc(C.Structure):
+    """mgx_conv_desc of include/mgx.h."""
+    _fields_ = [
+        ("nimg", C.c_int32), ("hin", C.c_int32), ("win", C.c_int32), ("cin", C.c_int32),
+        ("hout", C.c_int32), ("wout", C.c_int32),
+        ("kh", C.c_int32), ("kw", C.c_int32), ("sh", C.c_int32), ("sw", C.c_int32),
+        ("pt", C.c_int32), ("pl", C.c_int32),
+        ("flip", C.c_int32),
+        ("ngemm", C.c_int32),
+        ("dkh", C.c_int32), ("dkw", C.c_int32), ("cout", C.c_int32),
+        ("wsk", C.c_int32), ("wsn", C.c_int32),
+        ("wtap", C.c_int64),
+        ("nbias", C.c_int32),
+        ("accumulate", C.c_int32),
+        ("act_alpha", C.c_float),
+    ]
+
+
+_P = C.c_void_p
+_I64 = C.c_int64
+_I = C.c_int
+_F = C.c_float
+_DESC = C.POINTER(ConvDesc)
+
+# name -> (restype, argtypes); mirrors include/mgx.h one to one
+PROTOTYPES = {
+    "mgx_version": (_I, []),
+    "mgx_conv_gemm_f32": (_I, [_DESC, _P, _P, _P, _P, _P, _P, _P]),
+    "mgx_conv_wgrad_workspace": (_I64, [_DESC]),
+    "mgx_conv_wgrad_f32": (_I, [_DESC, _P, _P, _P, _P, _P, _P, _I64, _P]),
+    "mgx_upsample2x_fwd": (_I, [_P, _P, _I64, _I, _I, _I, _P]),
+    "mgx_upsample2x_bwd": (_I, [_P, _P, _I64, _I, _I, _I, _I, _P]),
+    "mgx_avgpool2x_fwd": (_I, [_P, _P, _I64, _I, _I, _I, _P]),
+    "mgx_avgpool2x_bwd": (_I, [_P, _P, _I64, _I, _I, _I, _I, _P]),
+    "mgx_add_n": (_I, [C.POINTER(_P), _I, _P, _I64, _P]),
+    "mgx_add_inplace": (_I, [_P, _P, _I64, _P]),
+    "mgx_weighted_sum_fwd": (_I, [_P, _P, _P, _P, _I64, _P]),
+    "mgx_weighted_sum_bwd": (_I, [_P, _P, _P, _P, _P, _I, _P, _I, _P, _P, _I64, _I64, _P]),
+    "mgx_reduce_workspace": (_I64, []),
+    "mgx_layernorm_workspace": (_I64, [_I64, _I64]),
+    "mgx_layernorm_fwd": (_I, [_P, _P, _P, _P, _P, _I64, _I64, _F, _P, _I64, _P]),
+    "mgx_layernorm_bwd": (_I, [_P, _P, _P, _P, _P, _I, _P, _P, _I64, _I64, _P, _I64, _P]),
+    "mgx_mbstd_workspace": (_I64, [_I64, _I64]),
+    "mgx_mbstd_fwd": (_I, [_P, _P, _P, _I64, _I, _I, _I, _P, _I64, _P]),
+    "mgx_mbstd_bwd": (_I, [_P, _P, _P, _I64, _I, _I, _I, _P, _I64, _P]),
+    "mgx_softrect_fwd": (_I, [_P, _P, _I64, _F, _P]),
+    "mgx_softrect_bwd": (_I, [_P, _P, _P, _I, _I64, _F, _P]),
+    "mgx_dense1_fwd": (_I, [_P, _P, _P, _P, _I64, _I64, _P]),
+    "mgx_dense1_bwd": (_I, [_P, _P, _P, _P, _P, _P, _I64, _I64, _P]),
+    "mgx_logit_sums": (_I, [_P, _P, _I64, _P, _P]),
+    "mgx_wgan_loss": (_I, [_P, _I64, _I, _P, _P, _P, _I64, _P]),
+    "mgx_adam_multi": (_I, [_P, _P, _P, _P, _P, _P, _P, _I64, _F, _F, _F, _P]),
+}
+
+_lib = None
+
+
+def load():
+    """Load libmgx.so (built by `make -C music_generator_amd/csrc`); raises if absent."""
+    global _lib
+    if _lib is not None:
+        return _lib
+    if not os.path.exists(LIB_PATH):
+        raise MgxError(
+            "libmgx.so not found at %s: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+            "(there is no CPU or PyTorch fallback for this path)" % LIB_PATH)
+    lib = C.CDLL(LIB_PATH)
+    for name, (res, args) in PROTOTYPES.items():
+        fn = getattr(lib, name)     # AttributeError if the symbol is missing
+        fn.restype = res
+        fn.argtypes = args
+    _lib = lib
+    return lib
+
+
+def check(status: int, what: str):
+    if status != MGX_OK:
+        raise MgxError("%s failed: %s (status %d)" % (what, _ERR.get(status, "unknown"), status))

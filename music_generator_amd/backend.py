@@ -1,0 +1,128 @@
+"""Host-side plumbing shared by the layer objects: Keras-style unique layer names, variables that
+live in HBM, the device handle and a reusable workspace.  PyTorch is used here only to allocate
+device memory, obtain the HIP stream and copy between host and device.
+"""
+from __future__ import annotations
+
+import re
+from typing import Dict, Optional, Tuple
+
+import numpy as np
+import torch
+
+_name_counts: Dict[str, int] = {}
+
+
+def clear_session():
+    """Reset the auto-naming counters (keras.backend.clear_session analogue)."""
+    _name_counts.clear()
+
+
+def unique_name(cls_name: str) -> str:
+    """Keras auto-name: snake_case class name, then _1, _2, ... per class."""
+    s = re.sub(r"(.)([A-Z][a-z0-9]+)", r"\1_\2", cls_name)
+    base = re.sub(r"([a-z])([A-Z])", r"\1_\2", s).lower()
+    i = _name_counts.get(base, 0)
+    _name_counts[base] = i + 1
+    return base if i == 0 else "%s_%d" % (base, i)
+
+
+def device() -> torch.device:
+    """The MI355X this process drives.  Raises when no GPU is visible: the layer kernels exist
+    only as gfx950 code objects and there is no host fallback."""
+    if not torch.cuda.is_available():
+        raise RuntimeError("music_generator_amd needs a ROCm GPU (MI355X / gfx950): no device visible")
+    return torch.device("cuda", torch.cuda.current_device())
+
+
+def stream_ptr() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+class Variable:
+    """A trainable tensor.  Created on the host (numpy) and moved to HBM the first time a model
+    that owns it runs; `grad` is a view into the flat gradient buffer of the model currently
+    being differentiated (bound by Model.bind_grads)."""
+
+    def __init__(self, name: str, value: np.ndarray, trainable: bool = True):
+        self.name = name
+        self.shape: Tuple[int, ...] = tuple(np.shape(value))
+        self.trainable = trainable
+        self._host: Optional[np.ndarray] = np.ascontiguousarray(value, dtype=np.float32)
+        self._dev: Optional[torch.Tensor] = None
+        self.grad: Optional[torch.Tensor] = None
+
+    @property
+    def size(self) -> int:
+        n = 1
+        for s in self.shape:
+            n *= s
+        return n
+
+    def value(self) -> torch.Tensor:
+        if self._dev is None:
+            host = self._host.reshape(-1) if self.shape else self._host.reshape(1)
+            self._dev = torch.from_numpy(host).to(device())
+            self._host = None
+        return self._dev
+
+    def numpy(self) -> np.ndarray:
+        if self._dev is not None:
+            return self._dev.detach().cpu().numpy().reshape(self.shape).copy()
+        return self._host.reshape(self.shape).copy()
+
+    def assign(self, value):
+        arr = np.ascontiguousarray(np.broadcast_to(np.asarray(value, dtype=np.float32), self.shape))
+        if self._dev is not None:
+            self._dev.copy_(torch.from_numpy(arr.reshape(-1) if self.shape else arr.reshape(1)))
+        else:
+            self._host = arr.copy()
+
+    def fill(self, scalar: float):
+        """Set every element to a host scalar without a host<->device synchronisation."""
+        if self._dev is not None:
+            self._dev.fill_(float(scalar))
+        else:
+            self._host = np.full(self.shape, scalar, dtype=np.float32)
+
+
+def variable(value, name: str = "variable") -> Variable:
+    """keras.backend.variable analogue (trainable by default, as in models.py:27)."""
+    return Variable(name, np.asarray(value, dtype=np.float32))
+
+
+def set_value(var: Variable, value):
+    """keras.backend.set_value analogue (models.py:82)."""
+    if np.ndim(value) == 0:
+        var.fill(float(value))
+    else:
+        var.assign(value)
+
+
+def get_value(var: Variable):
+    return var.numpy()
+
+
+_workspace: Dict[int, torch.Tensor] = {}
+
+
+def workspace(nbytes: int) -> torch.Tensor:
+    """A reusable scratch buffer of at least `nbytes` on the current device.  All kernels run on
+    one stream, so consecutive users are ordered."""
+    dev = device()
+    key = dev.index or 0
+    cur = _workspace.get(key)
+    if cur is None or cur.numel() < nbytes:
+        cur = None
+        _workspace.pop(key, None)
+        cur = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=dev)
+        _workspace[key] = cur
+    return cur
+
+
+def empty(shape, dev=None) -> torch.Tensor:
+    return torch.empty(tuple(int(s) for s in shape), dtype=torch.float32, device=dev or device())
+
+
+def zeros(shape, dev=None) -> torch.Tensor:
+    return torch.zeros(tuple(int(s) for s in shape), dtype=torch.float32, device=dev or device())

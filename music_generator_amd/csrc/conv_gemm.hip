@@ -1,0 +1,222 @@
+// Implicit-GEMM forward / data-gradient contraction on v_mfma_f32_32x32x2_f32 (gfx950).
+//
+// One wave owns PT tiles of 32 consecutive GEMM rows (output positions) and NT tiles of 32 GEMM
+// columns.  The A operand (activations) is read straight from global memory as one float4 per
+// lane along the contraction axis (lane half h takes k0+4h..k0+4h+3 of row l&31), the B operand
+// (weights, L2 resident) as four dwords (row-major [k][n]) or one float4 ([n][k]) per lane.  The
+// order in which k is consumed is free, so step j of a chunk pairs k0+j (lanes 0-31) with
+// k0+4+j (lanes 32-63) on both operands.  No LDS: the f32 MFMA takes 64 cycles per SIMD, which
+// leaves the load path far from saturated.
+#include "common.h"
+#include "../../include/mgx.h"
+
+namespace {
+
+struct RowPos {
+    long img;
+    int ho, wo;
+};
+
+__device__ __forceinline__ RowPos decode_row(long row, int hout, int wout) {
+    const int hw = hout * wout;
+    RowPos p;
+    p.img = row / hw;
+    const int rem = (int)(row - p.img * hw);
+    p.ho = rem / wout;
+    p.wo = rem - p.ho * wout;
+    return p;
+}
+
+template <int PT, int NT, int WMODE, bool KVEC>
+__global__ __launch_bounds__(256) void conv_gemm_kernel(mgx_conv_desc d, const float* __restrict__ x,
+                                                        const float* __restrict__ xmul,
+                                                        const float* __restrict__ w,
+                                                        const float* __restrict__ bias, float* __restrict__ y,
+                                                        float* __restrict__ dact) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const long R = (long)d.nimg * d.hout * d.wout;
+    const long row0 = ((long)blockIdx.x * 4 + wv) * (PT * 32);
+    if (row0 >= R) return;  // wave-uniform
+    const int n0 = blockIdx.y * (NT * 32);
+
+    bool valid[PT];
+    long img[PT];
+    int ho[PT], wo[PT];
+#pragma unroll
+    for (int pt = 0; pt < PT; ++pt) {
+        const long row = row0 + pt * 32 + r;
+        valid[pt] = row < R;
+        const RowPos p = decode_row(valid[pt] ? row : 0, d.hout, d.wout);
+        img[pt] = p.img; ho[pt] = p.ho; wo[pt] = p.wo;
+    }
+
+    f32x16 acc[PT][NT];
+#pragma unroll
+    for (int pt = 0; pt < PT; ++pt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[pt][nt][i] = 0.f;
+
+    int ncol[NT];
+    bool nok[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        ncol[nt] = n0 + nt * 32 + r;
+        nok[nt] = ncol[nt] < d.ngemm;
+    }
+
+    for (int a = 0; a < d.kh; ++a) {
+        for (int b = 0; b < d.kw; ++b) {
+            const int wt = d.flip ? ((d.kh - 1 - a) * d.kw + (d.kw - 1 - b)) : (a * d.kw + b);
+            const float* wtap = w + (long)wt * d.wtap;
+            bool ok[PT];
+            long xoff[PT];
+#pragma unroll
+            for (int pt = 0; pt < PT; ++pt) {
+                const int hi = ho[pt] * d.sh + a - d.pt;
+                const int wi = wo[pt] * d.sw + b - d.pl;
+                ok[pt] = valid[pt] && hi >= 0 && hi < d.hin && wi >= 0 && wi < d.win;
+                xoff[pt] = ((img[pt] * d.hin + hi) * d.win + wi) * (long)d.cin;
+            }
+            for (int k0 = 0; k0 < d.cin; k0 += 8) {
+                const int kk = k0 + 4 * h;
+                f32x4 xa[PT];
+#pragma unroll
+                for (int pt = 0; pt < PT; ++pt) {
+                    xa[pt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                    if (ok[pt]) {
+                        if (KVEC) {
+                            xa[pt] = *(const f32x4*)(x + xoff[pt] + kk);
+                            if (xmul) xa[pt] *= *(const f32x4*)(xmul + xoff[pt] + kk);
+                        } else {
+#pragma unroll
+                            for (int j = 0; j < 4; ++j)
+                                if (kk + j < d.cin) {
+                                    float v = x[xoff[pt] + kk + j];
+                                    if (xmul) v *= xmul[xoff[pt] + kk + j];
+                                    xa[pt][j] = v;
+                                }
+                        }
+                    }
+                }
+                f32x4 wb[NT];
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) {
+                    wb[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+                    if (nok[nt]) {
+                        if (WMODE == 0) {
+#pragma unroll
+                            for (int j = 0; j < 4; ++j)
+                                if (KVEC || kk + j < d.cin) wb[nt][j] = wtap[(long)(kk + j) * d.wsk + ncol[nt]];
+                        } else {
+                            if (KVEC) {
+                                wb[nt] = *(const f32x4*)(wtap + (long)ncol[nt] * d.wsn + kk);
+                            } else {
+#pragma unroll
+                                for (int j = 0; j < 4; ++j)
+                                    if (kk + j < d.cin) wb[nt][j] = wtap[(long)ncol[nt] * d.wsn + kk + j];
+                            }
+                        }
+                    }
+                }
+#pragma unroll
+                for (int j = 0; j < 4; ++j)
+#pragma unroll
+                    for (int pt = 0; pt < PT; ++pt)
+#pragma unroll
+                        for (int nt = 0; nt < NT; ++nt) acc[pt][nt] = mfma32(xa[pt][j], wb[nt][j], acc[pt][nt]);
+            }
+        }
+    }
+
+    // ---- epilogue: bias, activation, depth-to-space store ----
+    const bool scatter = (d.dkh * d.dkw) != 1;
+    const float inv_alpha = d.act_alpha > 0.f ? 1.0f / d.act_alpha : 0.f;
+    const long out_w = (long)d.wout * d.dkw;
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        if (!nok[nt]) continue;
+        const int n = ncol[nt];
+        const float bv = d.nbias > 0 ? bias[n % d.nbias] : 0.f;
+        long npart = n;
+        if (scatter) {
+            const int ab = n / d.cout, co = n - ab * d.cout;
+            const int a2 = ab / d.dkw, b2 = ab - a2 * d.dkw;
+            npart = (a2 * out_w + b2) * d.cout + co;
+        }
+#pragma unroll
+        for (int pt = 0; pt < PT; ++pt) {
+            const long rbase = row0 + pt * 32;
+            RowPos p0;
+            if (scatter) p0 = decode_row(rbase, d.hout, d.wout);
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                const int rl = acc_row(reg, lane);
+                const long row = rbase + rl;
+                if (row >= R) continue;
+                long off;
+                if (scatter) {
+                    long im = p0.img;
+                    int hh = p0.ho, ww = p0.wo + rl;
+                    while (ww >= d.wout) { ww -= d.wout; ++hh; }
+                    while (hh >= d.hout) { hh -= d.hout; ++im; }
+                    off = ((im * d.hout + hh) * d.dkh * out_w + (long)ww * d.dkw) * d.cout + npart;
+                } else {
+                    off = row * d.ngemm + npart;
+                }
+                float v = acc[pt][nt][reg] + bv;
+                if (d.act_alpha > 0.f) {
+                    float t, s2;
+                    tanh_sech2(v, t, s2);
+                    if (dact) dact[off] = s2 + inv_alpha;
+                    v = t + v / d.act_alpha;
+                }
+                if (d.accumulate) v += y[off];
+                y[off] = v;
+            }
+        }
+    }
+}
+
+template <int PT, int NT>
+int launch_pn(const mgx_conv_desc& d, const float* x, const float* xmul, const float* w, const float* bias,
+              float* y, float* dact, hipStream_t st) {
+    const long R = (long)d.nimg * d.hout * d.wout;
+    const long rows_per_block = 4L * PT * 32;
+    const long gx = (R + rows_per_block - 1) / rows_per_block;
+    const int gy = (d.ngemm + NT * 32 - 1) / (NT * 32);
+    if (gx <= 0 || gx > 0x7fffffffL) return MGX_ERR_ARG;
+    dim3 grid((unsigned)gx, (unsigned)gy), block(256);
+    const bool kvec = (d.cin % 8) == 0;
+    const int wmode = (d.wsn == 1) ? 0 : 1;
+    if (wmode == 0) {
+        if (kvec) hipLaunchKernelGGL((conv_gemm_kernel<PT, NT, 0, true>), grid, block, 0, st, d, x, xmul, w, bias, y, dact);
+        else hipLaunchKernelGGL((conv_gemm_kernel<PT, NT, 0, false>), grid, block, 0, st, d, x, xmul, w, bias, y, dact);
+    } else {
+        if (kvec) hipLaunchKernelGGL((conv_gemm_kernel<PT, NT, 1, true>), grid, block, 0, st, d, x, xmul, w, bias, y, dact);
+        else hipLaunchKernelGGL((conv_gemm_kernel<PT, NT, 1, false>), grid, block, 0, st, d, x, xmul, w, bias, y, dact);
+    }
+    return mgx_launch_status();
+}
+
+}  // namespace
+
+extern "C" int mgx_conv_gemm_f32(const mgx_conv_desc* dp, const float* x, const float* xmul, const float* w,
+                                 const float* bias, float* y, float* dact, void* stream) {
+    if (!dp || !x || !w || !y) return MGX_ERR_ARG;
+    const mgx_conv_desc d = *dp;
+    if (d.nimg <= 0 || d.hin <= 0 || d.win <= 0 || d.cin <= 0 || d.hout <= 0 || d.wout <= 0) return MGX_ERR_ARG;
+    if (d.kh <= 0 || d.kw <= 0 || d.sh <= 0 || d.sw <= 0 || d.dkh <= 0 || d.dkw <= 0 || d.cout <= 0) return MGX_ERR_ARG;
+    if (d.ngemm != d.dkh * d.dkw * d.cout) return MGX_ERR_ARG;
+    if (d.wsk != 1 && d.wsn != 1) return MGX_ERR_ARG;
+    if (d.nbias > 0 && !bias) return MGX_ERR_ARG;
+    // the last gather position of every row grid must be reachable by construction of the layer:
+    // out-of-range positions are treated as zero padding, never dereferenced.
+    hipStream_t st = (hipStream_t)stream;
+    const int ntiles = (d.ngemm + 31) / 32;
+    if (ntiles == 1) return launch_pn<4, 1>(d, x, xmul, w, bias, y, dact, st);
+    if (ntiles == 2) return launch_pn<2, 2>(d, x, xmul, w, bias, y, dact, st);
+    return launch_pn<2, 4>(d, x, xmul, w, bias, y, dact, st);
+}

@@ -1,0 +1,261 @@
+// Weight / bias gradient of the implicit-GEMM contraction on v_mfma_f32_32x32x2_f32 (gfx950).
+//
+// dW[tap][k][n] = sum over GEMM rows r of X[gather(r,tap)][k] * dY[scatter(r,n)].
+// The contraction runs over rows, two per MFMA (lane half h takes row r+h); both operands are
+// read straight from global memory with the channel index on the lane, i.e. 128-byte coalesced
+// segments (NHWC keeps the channel innermost).  Rows are split over `splits` waves; every wave
+// keeps T*KT*NT accumulator tiles of 32(k) x 32(n) in registers for its whole row range and
+// stores them once as a partial slab.  A second kernel adds the slabs in split order (fixed
+// order => bitwise reproducible) into dW with the weight tensor's own strides.
+#include "common.h"
+#include "../../include/mgx.h"
+
+namespace {
+
+struct WgradPlan {
+    int T, KT, NT;          // tiles per wave: taps x k-tiles x n-tiles
+    int ntaps, ktot, ntot;  // totals
+    int tap_groups, k_groups, n_groups;
+    long splits;            // multiple of 4
+    long rows_per_split;    // even
+    long tiles_total;
+    long partial_floats, bias_floats;
+};
+
+WgradPlan make_plan(const mgx_conv_desc& d) {
+    WgradPlan p;
+    p.ntaps = d.kh * d.kw;
+    p.ktot = (d.cin + 31) / 32;
+    p.ntot = (d.ngemm + 31) / 32;
+    if (p.ntaps % 9 == 0) p.T = 9;
+    else if (p.ntaps % 8 == 0) p.T = 8;
+    else if (p.ntaps % 4 == 0) p.T = 4;
+    else p.T = 1;
+    if (p.T > 1) { p.KT = 1; p.NT = 1; }
+    else {
+        p.KT = p.ktot >= 2 ? 2 : 1;
+        p.NT = p.ntot >= 4 ? 4 : (p.ntot >= 2 ? 2 : 1);
+    }
+    p.tap_groups = p.ntaps / p.T;
+    p.k_groups = (p.ktot + p.KT - 1) / p.KT;
+    p.n_groups = (p.ntot + p.NT - 1) / p.NT;
+    const long groups = (long)p.tap_groups * p.k_groups * p.n_groups;
+    const long R = (long)d.nimg * d.hout * d.wout;
+    long s = 2048 / groups;
+    if (s < 4) s = 4;
+    const long smax = (R + 63) / 64;  // at least 64 rows per split
+    if (s > smax) s = smax;
+    s = ((s + 3) / 4) * 4;
+    p.splits = s;
+    long rps = (R + s - 1) / s;
+    rps += rps & 1;
+    p.rows_per_split = rps;
+    p.tiles_total = (long)p.ntaps * p.ktot * p.ntot;
+    p.partial_floats = p.splits * p.tiles_total * 1024;
+    p.bias_floats = p.splits * p.ntot * 64;
+    return p;
+}
+
+template <int T, int KT, int NT>
+__global__ __launch_bounds__(256) void wgrad_kernel(mgx_conv_desc d, const float* __restrict__ x,
+                                                    const float* __restrict__ dy,
+                                                    const float* __restrict__ dymul, float* __restrict__ partial,
+                                                    float* __restrict__ bpartial, int tap_groups, int k_groups,
+                                                    int ktot, int ntot, long rows_per_split, long tiles_total) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const long split = (long)blockIdx.x * 4 + wv;
+    int g = blockIdx.y;
+    const int tg = g % tap_groups; g /= tap_groups;
+    const int kg = g % k_groups;
+    const int ng = g / k_groups;
+    const int tap0 = tg * T, kt0 = kg * KT, nt0 = ng * NT;
+    const long R = (long)d.nimg * d.hout * d.wout;
+    const long rbeg = split * rows_per_split;
+    long rend = rbeg + rows_per_split;
+    if (rend > R) rend = R;
+
+    f32x16 acc[T][KT][NT];
+#pragma unroll
+    for (int t = 0; t < T; ++t)
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) acc[t][kt][nt][i] = 0.f;
+    float bsum[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) bsum[nt] = 0.f;
+
+    // column (n) part of the dY address, fixed per lane
+    const long out_w = (long)d.wout * d.dkw;
+    long npart[NT];
+    bool nok[NT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        const int n = (nt0 + nt) * 32 + r;
+        nok[nt] = (nt0 + nt) < ntot && n < d.ngemm;
+        const int nn = nok[nt] ? n : 0;
+        const int ab = nn / d.cout, co = nn - ab * d.cout;
+        const int a2 = ab / d.dkw, b2 = ab - a2 * d.dkw;
+        npart[nt] = (a2 * out_w + b2) * d.cout + co;
+    }
+    int kcol[KT];
+    bool kok[KT];
+#pragma unroll
+    for (int kt = 0; kt < KT; ++kt) {
+        kcol[kt] = (kt0 + kt) * 32 + r;
+        kok[kt] = (kt0 + kt) < ktot && kcol[kt] < d.cin;
+    }
+
+    if (rbeg < rend) {
+        // position of this lane's first row (rbeg + h), then advance by 2 rows per step
+        long row = rbeg + h;
+        const int hw = d.hout * d.wout;
+        long img = row / hw;
+        int rem = (int)(row - img * hw);
+        int ho = rem / d.wout;
+        int wo = rem - ho * d.wout;
+        for (; row - h < rend; row += 2) {
+            const bool rv = row < rend;
+            const long ybase = ((img * d.hout + ho) * d.dkh * out_w + (long)wo * d.dkw) * d.cout;
+            float bv[NT];
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                float v = 0.f;
+                if (rv && nok[nt]) {
+                    v = dy[ybase + npart[nt]];
+                    if (dymul) v *= dymul[ybase + npart[nt]];
+                }
+                bv[nt] = v;
+                bsum[nt] += v;
+            }
+#pragma unroll
+            for (int t = 0; t < T; ++t) {
+                const int tap = tap0 + t;
+                const int a = tap / d.kw, b = tap - a * d.kw;
+                const int hi = ho * d.sh + a - d.pt;
+                const int wi = wo * d.sw + b - d.pl;
+                const bool ok = rv && hi >= 0 && hi < d.hin && wi >= 0 && wi < d.win;
+                const long xoff = ((img * d.hin + hi) * d.win + wi) * (long)d.cin;
+                float av[KT];
+#pragma unroll
+                for (int kt = 0; kt < KT; ++kt) av[kt] = (ok && kok[kt]) ? x[xoff + kcol[kt]] : 0.f;
+#pragma unroll
+                for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) acc[t][kt][nt] = mfma32(av[kt], bv[nt], acc[t][kt][nt]);
+            }
+            wo += 2;
+            while (wo >= d.wout) { wo -= d.wout; ++ho; }
+            while (ho >= d.hout) { ho -= d.hout; ++img; }
+        }
+    }
+
+    // ---- store partial tiles: partial[((split*tiles_total + tile)*16 + reg)*64 + lane] ----
+#pragma unroll
+    for (int t = 0; t < T; ++t)
+#pragma unroll
+        for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                if ((kt0 + kt) >= ktot || (nt0 + nt) >= ntot) continue;
+                const long tile = ((long)(tap0 + t) * ktot + (kt0 + kt)) * ntot + (nt0 + nt);
+                float* dst = partial + ((split * tiles_total + tile) * 16) * 64 + lane;
+#pragma unroll
+                for (int reg = 0; reg < 16; ++reg) dst[reg * 64] = acc[t][kt][nt][reg];
+            }
+    if (bpartial && tg == 0 && kg == 0) {
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+            if ((nt0 + nt) < ntot) bpartial[(split * ntot + (nt0 + nt)) * 64 + lane] = bsum[nt];
+    }
+}
+
+// dW[tap*wtap + k*wsk + n*wsn] += sum_split partial[...]; one thread per (tap,k,n).
+__global__ __launch_bounds__(256) void wgrad_reduce_kernel(mgx_conv_desc d, const float* __restrict__ partial,
+                                                           float* __restrict__ dw, long splits, int ktot, int ntot,
+                                                           long tiles_total) {
+    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+    const long per_tap = (long)d.cin * d.ngemm;
+    const long total = (long)d.kh * d.kw * per_tap;
+    if (idx >= total) return;
+    const int tap = (int)(idx / per_tap);
+    const int rem = (int)(idx - tap * per_tap);
+    const int k = rem / d.ngemm, n = rem - k * d.ngemm;  // consecutive threads -> consecutive n
+    const long tile = ((long)tap * ktot + (k >> 5)) * ntot + (n >> 5);
+    const int i = k & 31, j = n & 31;
+    const int lane = j + 32 * ((i >> 2) & 1);
+    const int reg = (i & 3) + 4 * (i >> 3);
+    const float* src = partial + (tile * 16 + reg) * 64 + lane;
+    const long stride = tiles_total * 1024;
+    float s = 0.f;
+    for (long sp = 0; sp < splits; ++sp) s += src[sp * stride];
+    dw[(long)tap * d.wtap + (long)k * d.wsk + (long)n * d.wsn] += s;
+}
+
+// db[c] += sum over n == c (mod nbias), splits, lane halves.
+__global__ __launch_bounds__(64) void bias_reduce_kernel(mgx_conv_desc d, const float* __restrict__ bpartial,
+                                                         float* __restrict__ db, long splits, int ntot) {
+    const int c = blockIdx.x * 64 + threadIdx.x;
+    if (c >= d.nbias) return;
+    float s = 0.f;
+    for (int n = c; n < d.ngemm; n += d.nbias) {
+        const int nt = n >> 5, j = n & 31;
+        for (long sp = 0; sp < splits; ++sp) {
+            const float* src = bpartial + (sp * ntot + nt) * 64;
+            s += src[j] + src[j + 32];
+        }
+    }
+    db[c] += s;
+}
+
+template <int T, int KT, int NT>
+void launch_wgrad(const mgx_conv_desc& d, const WgradPlan& p, const float* x, const float* dy, const float* dymul,
+                  float* partial, float* bpartial, hipStream_t st) {
+    dim3 grid((unsigned)(p.splits / 4), (unsigned)(p.tap_groups * p.k_groups * p.n_groups)), block(256);
+    hipLaunchKernelGGL((wgrad_kernel<T, KT, NT>), grid, block, 0, st, d, x, dy, dymul, partial, bpartial,
+                       p.tap_groups, p.k_groups, p.ktot, p.ntot, p.rows_per_split, p.tiles_total);
+}
+
+}  // namespace
+
+extern "C" int64_t mgx_conv_wgrad_workspace(const mgx_conv_desc* dp) {
+    if (!dp) return -1;
+    const WgradPlan p = make_plan(*dp);
+    return (p.partial_floats + p.bias_floats) * (int64_t)sizeof(float);
+}
+
+extern "C" int mgx_conv_wgrad_f32(const mgx_conv_desc* dp, const float* x, const float* dy, const float* dymul,
+                                  float* dw, float* dbias, void* workspace, int64_t workspace_bytes, void* stream) {
+    if (!dp || !x || !dy || !dw || !workspace) return MGX_ERR_ARG;
+    const mgx_conv_desc d = *dp;
+    if (d.nimg <= 0 || d.cin <= 0 || d.hout <= 0 || d.wout <= 0 || d.kh <= 0 || d.kw <= 0) return MGX_ERR_ARG;
+    if (d.ngemm != d.dkh * d.dkw * d.cout) return MGX_ERR_ARG;
+    if (dbias && d.nbias <= 0) return MGX_ERR_ARG;
+    const WgradPlan p = make_plan(d);
+    if ((p.partial_floats + p.bias_floats) * (int64_t)sizeof(float) > workspace_bytes) return MGX_ERR_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    float* partial = (float*)workspace;
+    float* bpartial = dbias ? partial + p.partial_floats : nullptr;
+#define MGX_WG(TT, KK, NN) launch_wgrad<TT, KK, NN>(d, p, x, dy, dymul, partial, bpartial, st)
+    if (p.T == 9) MGX_WG(9, 1, 1);
+    else if (p.T == 8) MGX_WG(8, 1, 1);
+    else if (p.T == 4) MGX_WG(4, 1, 1);
+    else if (p.KT == 1 && p.NT == 1) MGX_WG(1, 1, 1);
+    else if (p.KT == 1 && p.NT == 2) MGX_WG(1, 1, 2);
+    else if (p.KT == 1 && p.NT == 4) MGX_WG(1, 1, 4);
+    else if (p.KT == 2 && p.NT == 1) MGX_WG(1, 2, 1);
+    else if (p.KT == 2 && p.NT == 2) MGX_WG(1, 2, 2);
+    else MGX_WG(1, 2, 4);
+#undef MGX_WG
+    if (hipGetLastError() != hipSuccess) return MGX_ERR_LAUNCH;
+    const long total = (long)d.kh * d.kw * d.cin * d.ngemm;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, d, partial, dw,
+                       p.splits, p.ktot, p.ntot, p.tiles_total);
+    if (dbias)
+        hipLaunchKernelGGL(bias_reduce_kernel, dim3((unsigned)((d.nbias + 63) / 64)), dim3(64), 0, st, d, bpartial,
+                           dbias, p.splits, p.ntot);
+    return mgx_launch_status();
+}

@@ -1,0 +1,443 @@
+// Reduction-shaped layers: LayerNormalization(axis=[1,2,3]), MinibatchStdDev, Flatten+Dense(1),
+// the WGAN losses and their logit-gradient seeds.  All cross-workgroup sums are two-stage with
+// fixed order (partials in a caller workspace, double precision), so results are reproducible.
+#include "common.h"
+#include "../../include/mgx.h"
+
+namespace {
+
+constexpr int kBlock = 256;
+
+inline long ln_blocks_per_sample(long nimg, long e) {
+    long b = 2048 / (nimg > 0 ? nimg : 1);
+    const long bmax = (e + 4095) / 4096;
+    if (b > bmax) b = bmax;
+    if (b < 1) b = 1;
+    return b;
+}
+
+// ---------------- LayerNormalization forward ----------------
+__global__ __launch_bounds__(kBlock) void ln_partial_kernel(const float* __restrict__ x, double* __restrict__ part,
+                                                            long e, long bps) {
+    __shared__ double red[4];
+    const long img = blockIdx.y;
+    const long b = blockIdx.x;
+    const long chunk = ((e + bps - 1) / bps + 3) & ~3L;
+    const long beg = b * chunk;
+    long end = beg + chunk;
+    if (end > e) end = e;
+    const float* src = x + img * e;
+    double s = 0.0, q = 0.0;
+    for (long i = beg + threadIdx.x; i < end; i += kBlock) {
+        const double v = (double)src[i];
+        s += v;
+        q += v * v;
+    }
+    const double ts = block_sum256_d(s, red);
+    const double tq = block_sum256_d(q, red);
+    if (threadIdx.x == 0) {
+        part[(img * bps + b) * 2] = ts;
+        part[(img * bps + b) * 2 + 1] = tq;
+    }
+}
+
+__global__ __launch_bounds__(64) void ln_stats_kernel(const double* __restrict__ part, float* __restrict__ stats, long e,
+                                                      long bps, float eps) {
+    const long img = blockIdx.x;
+    double s = 0.0, q = 0.0;
+    for (long b = threadIdx.x; b < bps; b += 64) {
+        s += part[(img * bps + b) * 2];
+        q += part[(img * bps + b) * 2 + 1];
+    }
+    s = wave_sum_d(s);
+    q = wave_sum_d(q);
+    if (threadIdx.x == 0) {
+        const double mean = s / (double)e;
+        double var = q / (double)e - mean * mean;
+        if (var < 0.0) var = 0.0;
+        stats[img * 2] = (float)mean;
+        stats[img * 2 + 1] = (float)(1.0 / sqrt(var + (double)eps));
+    }
+}
+
+__global__ __launch_bounds__(kBlock) void ln_apply_kernel(const float* __restrict__ x, const float* __restrict__ gamma,
+                                                          const float* __restrict__ beta,
+                                                          const float* __restrict__ stats, float* __restrict__ y,
+                                                          long e) {
+    const long img = blockIdx.y;
+    const float mean = stats[img * 2], rstd = stats[img * 2 + 1];
+    const float* src = x + img * e;
+    float* dst = y + img * e;
+    const long e2 = e / 2;  // e is always even (2 channels innermost)
+    for (long i = (long)blockIdx.x * kBlock + threadIdx.x; i < e2; i += (long)gridDim.x * kBlock) {
+        const float2 v = ((const float2*)src)[i], g = ((const float2*)gamma)[i], b = ((const float2*)beta)[i];
+        ((float2*)dst)[i] = make_float2((v.x - mean) * rstd * g.x + b.x, (v.y - mean) * rstd * g.y + b.y);
+    }
+    if ((e & 1) && blockIdx.x == 0 && threadIdx.x == 0)
+        dst[e - 1] = (src[e - 1] - mean) * rstd * gamma[e - 1] + beta[e - 1];
+}
+
+// ---------------- LayerNormalization backward ----------------
+// per-sample s1 = sum(dy*gamma), s2 = sum(dy*gamma*xhat)
+__global__ __launch_bounds__(kBlock) void ln_bwd_partial_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                                const float* __restrict__ gamma,
+                                                                const float* __restrict__ stats,
+                                                                double* __restrict__ part, long e, long bps) {
+    __shared__ double red[4];
+    const long img = blockIdx.y;
+    const long b = blockIdx.x;
+    const long chunk = ((e + bps - 1) / bps + 3) & ~3L;
+    const long beg = b * chunk;
+    long end = beg + chunk;
+    if (end > e) end = e;
+    const float mean = stats[img * 2], rstd = stats[img * 2 + 1];
+    const float* g = dy + img * e;
+    const float* src = x + img * e;
+    double s1 = 0.0, s2 = 0.0;
+    for (long i = beg + threadIdx.x; i < end; i += kBlock) {
+        const float gg = g[i] * gamma[i];
+        const float xh = (src[i] - mean) * rstd;
+        s1 += (double)gg;
+        s2 += (double)gg * (double)xh;
+    }
+    const double t1 = block_sum256_d(s1, red);
+    const double t2 = block_sum256_d(s2, red);
+    if (threadIdx.x == 0) {
+        part[(img * bps + b) * 2] = t1;
+        part[(img * bps + b) * 2 + 1] = t2;
+    }
+}
+
+__global__ __launch_bounds__(64) void ln_bwd_sums_kernel(const double* __restrict__ part, float* __restrict__ sums,
+                                                         long e, long bps) {
+    const long img = blockIdx.x;
+    double s = 0.0, q = 0.0;
+    for (long b = threadIdx.x; b < bps; b += 64) {
+        s += part[(img * bps + b) * 2];
+        q += part[(img * bps + b) * 2 + 1];
+    }
+    s = wave_sum_d(s);
+    q = wave_sum_d(q);
+    if (threadIdx.x == 0) {
+        sums[img * 2] = (float)(s / (double)e);
+        sums[img * 2 + 1] = (float)(q / (double)e);
+    }
+}
+
+// one thread per element position, loop over the batch: dx for every sample, dgamma/dbeta sums.
+__global__ __launch_bounds__(kBlock) void ln_bwd_apply_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                              const float* __restrict__ gamma,
+                                                              const float* __restrict__ stats,
+                                                              const float* __restrict__ sums, float* __restrict__ dx,
+                                                              int acc_x, float* __restrict__ dgamma,
+                                                              float* __restrict__ dbeta, long nimg, long e) {
+    for (long i = (long)blockIdx.x * kBlock + threadIdx.x; i < e; i += (long)gridDim.x * kBlock) {
+        const float gm = gamma[i];
+        float dg = 0.f, db = 0.f;
+        for (long n = 0; n < nimg; ++n) {
+            const float mean = stats[n * 2], rstd = stats[n * 2 + 1];
+            const float m1 = sums[n * 2], m2 = sums[n * 2 + 1];
+            const long o = n * e + i;
+            const float g = dy[o];
+            const float xh = (x[o] - mean) * rstd;
+            dg += g * xh;
+            db += g;
+            if (dx) {
+                const float v = rstd * (g * gm - m1 - xh * m2);
+                dx[o] = acc_x ? dx[o] + v : v;
+            }
+        }
+        if (dgamma) dgamma[i] += dg;
+        if (dbeta) dbeta[i] += db;
+    }
+}
+
+// ---------------- MinibatchStdDev ----------------
+inline long mb_blocks(long e) {
+    long b = (e + 2047) / 2048;
+    if (b > 256) b = 256;
+    if (b < 1) b = 1;
+    return b;
+}
+
+// grid (B, M): partial sums of sqrt(var_g + 1e-8) over a chunk of element positions.
+__global__ __launch_bounds__(kBlock) void mb_partial_kernel(const float* __restrict__ x, double* __restrict__ part,
+                                                            long e, int g, long m_groups, long bps) {
+    __shared__ double red[4];
+    const long m = blockIdx.y, b = blockIdx.x;
+    const long chunk = (e + bps - 1) / bps;
+    const long beg = b * chunk;
+    long end = beg + chunk;
+    if (end > e) end = e;
+    double s = 0.0;
+    for (long i = beg + threadIdx.x; i < end; i += kBlock) {
+        float v[4];
+        float mean = 0.f;
+        for (int k = 0; k < g; ++k) { v[k] = x[(k * m_groups + m) * e + i]; mean += v[k]; }
+        mean /= (float)g;
+        float var = 0.f;
+        for (int k = 0; k < g; ++k) { const float d = v[k] - mean; var += d * d; }
+        var /= (float)g;
+        s += (double)sqrtf(var + 1e-8f);
+    }
+    const double t = block_sum256_d(s, red);
+    if (threadIdx.x == 0) part[m * bps + b] = t;
+}
+
+__global__ __launch_bounds__(64) void mb_stat_kernel(const double* __restrict__ part, float* __restrict__ stat, long e,
+                                                     long bps) {
+    const long m = blockIdx.x;
+    double s = 0.0;
+    for (long b = threadIdx.x; b < bps; b += 64) s += part[m * bps + b];
+    s = wave_sum_d(s);
+    if (threadIdx.x == 0) stat[m] = (float)(s / (double)e);
+}
+
+// y[i, 0:e] = x[i];  y[i, e:e+row] = stat[i % M]
+__global__ __launch_bounds__(kBlock) void mb_write_kernel(const float* __restrict__ x, const float* __restrict__ stat,
+                                                          float* __restrict__ y, long e, long row, long m_groups) {
+    const long i = blockIdx.y;
+    const float s = stat[i % m_groups];
+    const float* src = x + i * e;
+    float* dst = y + i * (e + row);
+    for (long j = (long)blockIdx.x * kBlock + threadIdx.x; j < e + row; j += (long)gridDim.x * kBlock)
+        dst[j] = j < e ? src[j] : s;
+}
+
+// dstat[m] = sum over members i (i % M == m) and the appended row of dy
+__global__ __launch_bounds__(kBlock) void mb_dstat_kernel(const float* __restrict__ dy, float* __restrict__ dstat, long e,
+                                                          long row, int g, long m_groups) {
+    __shared__ double red[4];
+    const long m = blockIdx.x;
+    double s = 0.0;
+    for (int k = 0; k < g; ++k) {
+        const float* src = dy + (k * m_groups + m) * (e + row) + e;
+        for (long j = threadIdx.x; j < row; j += kBlock) s += (double)src[j];
+    }
+    const double t = block_sum256_d(s, red);
+    if (threadIdx.x == 0) dstat[m] = (float)t;
+}
+
+// dx[i,j] = dy[i,j] + dstat[m] * (x[i,j]-mean_j) / (g * std_j * e)
+__global__ __launch_bounds__(kBlock) void mb_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                        const float* __restrict__ dstat, float* __restrict__ dx, long e,
+                                                        long row, int g, long m_groups) {
+    const long m = blockIdx.y;
+    const float ds = dstat[m] / ((float)g * (float)e);
+    for (long i = (long)blockIdx.x * kBlock + threadIdx.x; i < e; i += (long)gridDim.x * kBlock) {
+        float v[4];
+        float mean = 0.f;
+        for (int k = 0; k < g; ++k) { v[k] = x[(k * m_groups + m) * e + i]; mean += v[k]; }
+        mean /= (float)g;
+        float var = 0.f;
+        for (int k = 0; k < g; ++k) { const float d = v[k] - mean; var += d * d; }
+        var /= (float)g;
+        const float inv_std = 1.0f / sqrtf(var + 1e-8f);
+        for (int k = 0; k < g; ++k) {
+            const long smp = k * m_groups + m;
+            dx[smp * e + i] = dy[smp * (e + row) + i] + ds * (v[k] - mean) * inv_std;
+        }
+    }
+}
+
+// ---------------- Flatten + Dense(1) ----------------
+__global__ __launch_bounds__(kBlock) void dense1_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                            const float* __restrict__ b, float* __restrict__ y, long e) {
+    __shared__ double red[4];
+    const long i = blockIdx.x;
+    const float* src = x + i * e;
+    double s = 0.0;
+    const long e4 = e / 4;
+    for (long j = threadIdx.x; j < e4; j += kBlock) {
+        const float4 a = ((const float4*)src)[j], c = ((const float4*)w)[j];
+        s += (double)a.x * c.x + (double)a.y * c.y + (double)a.z * c.z + (double)a.w * c.w;
+    }
+    for (long j = e4 * 4 + threadIdx.x; j < e; j += kBlock) s += (double)src[j] * w[j];
+    const double t = block_sum256_d(s, red);
+    if (threadIdx.x == 0) y[i] = (float)(t + (double)(b ? b[0] : 0.f));
+}
+
+__global__ __launch_bounds__(kBlock) void dense1_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
+                                                            const float* __restrict__ w, float* __restrict__ dx,
+                                                            float* __restrict__ dw, float* __restrict__ db, long n,
+                                                            long e) {
+    for (long j = (long)blockIdx.x * kBlock + threadIdx.x; j < e; j += (long)gridDim.x * kBlock) {
+        const float wj = w[j];
+        float acc = 0.f;
+        for (long i = 0; i < n; ++i) {
+            const float g = dy[i];
+            if (dx) dx[i * e + j] = g * wj;
+            if (dw) acc += g * x[i * e + j];
+        }
+        if (dw) dw[j] += acc;
+    }
+    if (db && blockIdx.x == 0 && threadIdx.x == 0) {
+        float s = 0.f;
+        for (long i = 0; i < n; ++i) s += dy[i];
+        db[0] += s;
+    }
+}
+
+// ---------------- losses ----------------
+__global__ __launch_bounds__(kBlock) void logit_sums_kernel(const float* __restrict__ fake, const float* __restrict__ real,
+                                                            long n, float* __restrict__ sums) {
+    __shared__ double red[4];
+    double sf = 0.0, sr = 0.0;
+    for (long i = threadIdx.x; i < n; i += kBlock) {
+        if (fake) sf += (double)fake[i];
+        if (real) sr += (double)real[i];
+    }
+    const double tf = block_sum256_d(sf, red);
+    const double tr = block_sum256_d(sr, red);
+    if (threadIdx.x == 0) { sums[0] = (float)tf; sums[1] = (float)tr; }
+}
+
+__global__ __launch_bounds__(kBlock) void wgan_loss_kernel(const float* __restrict__ sums, long n_global, int mode,
+                                                           float* __restrict__ out4, float* __restrict__ dfake,
+                                                           float* __restrict__ dreal, long n_local) {
+    const float cu = sums[0] / (float)n_global;
+    const float ci = sums[1] / (float)n_global;
+    const float lamb = cu - ci;
+    const float delta = fabsf(lamb);
+    const float sgn = delta == 0.f ? 0.f : lamb / delta;  // divide_no_nan
+    const float inv_n = 1.0f / (float)n_global;
+    float loss, gf, gr;
+    if (mode == 0) {
+        const float sign = sgn + 0.0001f;
+        const float sign2 = (sgn + 0.0000999f) * -1.0f;
+        loss = sign * ci + sign2 * cu;
+        gr = sign * inv_n;
+        gf = sign2 * inv_n;
+    } else {
+        const float sign = sgn + 0.0001f;
+        loss = sign * ci + delta;
+        gr = 0.f;
+        gf = sgn * inv_n;
+    }
+    if (threadIdx.x == 0 && out4) { out4[0] = loss; out4[1] = cu; out4[2] = ci; out4[3] = delta; }
+    for (long i = threadIdx.x; i < n_local; i += kBlock) {
+        if (dfake) dfake[i] = gf;
+        if (dreal) dreal[i] = gr;
+    }
+}
+
+}  // namespace
+
+extern "C" int64_t mgx_layernorm_workspace(int64_t nimg, int64_t e) {
+    if (nimg <= 0 || e <= 0) return -1;
+    const long bps = ln_blocks_per_sample(nimg, e);
+    return nimg * bps * 2 * (int64_t)sizeof(double) + nimg * 2 * (int64_t)sizeof(float);
+}
+
+extern "C" int mgx_layernorm_fwd(const float* x, const float* gamma, const float* beta, float* y, float* stats,
+                                 int64_t nimg, int64_t e, float eps, void* workspace, int64_t workspace_bytes,
+                                 void* stream) {
+    if (!x || !gamma || !beta || !y || !stats || !workspace || nimg <= 0 || e <= 0 || nimg > 65535) return MGX_ERR_ARG;
+    if (workspace_bytes < mgx_layernorm_workspace(nimg, e)) return MGX_ERR_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    const long bps = ln_blocks_per_sample(nimg, e);
+    double* part = (double*)workspace;
+    hipLaunchKernelGGL(ln_partial_kernel, dim3((unsigned)bps, (unsigned)nimg), dim3(kBlock), 0, st, x, part, (long)e, bps);
+    hipLaunchKernelGGL(ln_stats_kernel, dim3((unsigned)nimg), dim3(64), 0, st, part, stats, (long)e, bps, eps);
+    long gx = (e / 2 + kBlock - 1) / kBlock;
+    const long cap = 4096 / nimg > 0 ? 4096 / nimg : 1;
+    if (gx > cap) gx = cap;
+    if (gx < 1) gx = 1;
+    hipLaunchKernelGGL(ln_apply_kernel, dim3((unsigned)gx, (unsigned)nimg), dim3(kBlock), 0, st, x, gamma, beta, stats, y,
+                       (long)e);
+    return mgx_launch_status();
+}
+
+extern "C" int mgx_layernorm_bwd(const float* dy, const float* x, const float* gamma, const float* stats, float* dx,
+                                 int acc_x, float* dgamma, float* dbeta, int64_t nimg, int64_t e, void* workspace,
+                                 int64_t workspace_bytes, void* stream) {
+    if (!dy || !x || !gamma || !stats || !workspace || nimg <= 0 || e <= 0 || nimg > 65535) return MGX_ERR_ARG;
+    if (workspace_bytes < mgx_layernorm_workspace(nimg, e)) return MGX_ERR_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    const long bps = ln_blocks_per_sample(nimg, e);
+    double* part = (double*)workspace;
+    float* sums = (float*)(part + nimg * bps * 2);
+    hipLaunchKernelGGL(ln_bwd_partial_kernel, dim3((unsigned)bps, (unsigned)nimg), dim3(kBlock), 0, st, dy, x, gamma,
+                       stats, part, (long)e, bps);
+    hipLaunchKernelGGL(ln_bwd_sums_kernel, dim3((unsigned)nimg), dim3(64), 0, st, part, sums, (long)e, bps);
+    long gx = (e + kBlock - 1) / kBlock;
+    if (gx > 8192) gx = 8192;
+    hipLaunchKernelGGL(ln_bwd_apply_kernel, dim3((unsigned)gx), dim3(kBlock), 0, st, dy, x, gamma, stats, sums, dx, acc_x,
+                       dgamma, dbeta, (long)nimg, (long)e);
+    return mgx_launch_status();
+}
+
+extern "C" int64_t mgx_mbstd_workspace(int64_t n, int64_t e) {
+    if (n <= 0 || e <= 0) return -1;
+    const long g = n < 4 ? n : 4;
+    const long m = n / g;
+    return m * mb_blocks(e) * (int64_t)sizeof(double) + m * (int64_t)sizeof(float);
+}
+
+extern "C" int mgx_mbstd_fwd(const float* x, float* y, float* stat, int64_t n, int h, int w, int c, void* workspace,
+                             int64_t workspace_bytes, void* stream) {
+    if (!x || !y || !stat || !workspace || n <= 0 || h <= 0 || w <= 0 || c <= 0) return MGX_ERR_ARG;
+    const int g = n < 4 ? (int)n : 4;
+    if (n % g != 0) return MGX_ERR_ARG;  // the reference's reshape requires it (models.py:176)
+    const long m = n / g;
+    const long e = (long)h * w * c, row = (long)w * c;
+    if (m > 65535 || n > 65535) return MGX_ERR_ARG;
+    if (workspace_bytes < mgx_mbstd_workspace(n, e)) return MGX_ERR_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    const long bps = mb_blocks(e);
+    double* part = (double*)workspace;
+    hipLaunchKernelGGL(mb_partial_kernel, dim3((unsigned)bps, (unsigned)m), dim3(kBlock), 0, st, x, part, e, g, m, bps);
+    hipLaunchKernelGGL(mb_stat_kernel, dim3((unsigned)m), dim3(64), 0, st, part, stat, e, bps);
+    long gx = (e + row + kBlock - 1) / kBlock;
+    if (gx > 128) gx = 128;
+    hipLaunchKernelGGL(mb_write_kernel, dim3((unsigned)gx, (unsigned)n), dim3(kBlock), 0, st, x, stat, y, e, row, m);
+    return mgx_launch_status();
+}
+
+extern "C" int mgx_mbstd_bwd(const float* dy, const float* x, float* dx, int64_t n, int h, int w, int c, void* workspace,
+                             int64_t workspace_bytes, void* stream) {
+    if (!dy || !x || !dx || !workspace || n <= 0 || h <= 0 || w <= 0 || c <= 0) return MGX_ERR_ARG;
+    const int g = n < 4 ? (int)n : 4;
+    if (n % g != 0) return MGX_ERR_ARG;
+    const long m = n / g;
+    const long e = (long)h * w * c, row = (long)w * c;
+    if (m > 65535) return MGX_ERR_ARG;
+    if (workspace_bytes < mgx_mbstd_workspace(n, e)) return MGX_ERR_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    const long bps = mb_blocks(e);
+    float* dstat = (float*)((double*)workspace + m * bps);
+    hipLaunchKernelGGL(mb_dstat_kernel, dim3((unsigned)m), dim3(kBlock), 0, st, dy, dstat, e, row, g, m);
+    hipLaunchKernelGGL(mb_bwd_kernel, dim3((unsigned)bps, (unsigned)m), dim3(kBlock), 0, st, dy, x, dstat, dx, e, row, g, m);
+    return mgx_launch_status();
+}
+
+extern "C" int mgx_dense1_fwd(const float* x, const float* w, const float* b, float* y, int64_t n, int64_t e,
+                              void* stream) {
+    if (!x || !w || !y || n <= 0 || e <= 0 || n > 0x7fffffffL) return MGX_ERR_ARG;
+    hipLaunchKernelGGL(dense1_fwd_kernel, dim3((unsigned)n), dim3(kBlock), 0, (hipStream_t)stream, x, w, b, y, (long)e);
+    return mgx_launch_status();
+}
+
+extern "C" int mgx_dense1_bwd(const float* dy, const float* x, const float* w, float* dx, float* dw, float* db,
+                              int64_t n, int64_t e, void* stream) {
+    if (!dy || !x || !w || n <= 0 || e <= 0) return MGX_ERR_ARG;
+    long gx = (e + kBlock - 1) / kBlock;
+    if (gx > 4096) gx = 4096;
+    hipLaunchKernelGGL(dense1_bwd_kernel, dim3((unsigned)gx), dim3(kBlock), 0, (hipStream_t)stream, dy, x, w, dx, dw, db,
+                       (long)n, (long)e);
+    return mgx_launch_status();
+}
+
+extern "C" int mgx_logit_sums(const float* fake, const float* real, int64_t n, float* sums, void* stream) {
+    if (!sums || n <= 0 || (!fake && !real)) return MGX_ERR_ARG;
+    hipLaunchKernelGGL(logit_sums_kernel, dim3(1), dim3(kBlock), 0, (hipStream_t)stream, fake, real, (long)n, sums);
+    return mgx_launch_status();
+}
+
+extern "C" int mgx_wgan_loss(const float* sums, int64_t n_global, int mode, float* out4, float* dfake, float* dreal,
+                             int64_t n_local, void* stream) {
+    if (!sums || n_global <= 0 || (mode != 0 && mode != 1) || n_local < 0) return MGX_ERR_ARG;
+    hipLaunchKernelGGL(wgan_loss_kernel, dim3(1), dim3(kBlock), 0, (hipStream_t)stream, sums, (long)n_global, mode, out4,
+                       dfake, dreal, (long)n_local);
+    return mgx_launch_status();
+}

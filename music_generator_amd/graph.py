@@ -1,0 +1,376 @@
+"""A minimal functional-graph engine with the surface of keras.Model that trainer/models.py and
+trainer/task.py rely on: symbolic tensors, layers that record their calls, `Model(inputs,
+outputs)` with `.layers` (input first, ordered by depth), `.input`, `.output_shape`,
+`.trainable_variables`, `__call__` / `predict`, plus an explicit tape: `forward(x, save=True)`
+returns the saved activations and `backward(tape, dy, ...)` walks the plan in reverse.
+
+Execution is a flat plan of kernel launches (no tracing, no autograd).  A contraction layer
+followed only by a SoftRectifier / StaticOptTanh is run as one fused kernel.
+"""
+from __future__ import annotations
+
+from typing import Dict, List, Optional, Sequence, Tuple
+
+import numpy as np
+import torch
+
+from . import backend as K
+from . import ops
+
+
+class _ShapeOnly:
+    def __init__(self, shape):
+        self.shape = tuple(shape)
+
+
+class KTensor:
+    """Symbolic tensor: shape with a leading None batch dimension."""
+
+    def __init__(self, shape: Tuple, node: Optional["Node"]):
+        self.shape = tuple(shape)
+        self.node = node
+
+    def __getitem__(self, idx):
+        # old_model.input[0].shape is used by add_discriminator_block (models.py:231)
+        if idx == 0:
+            return _ShapeOnly(self.shape[1:])
+        raise IndexError("only [0] (drop the batch axis) is supported on a symbolic tensor")
+
+
+class Node:
+    def __init__(self, layer: "Layer", inputs: List[KTensor]):
+        self.layer = layer
+        self.inputs = inputs
+        self.output: Optional[KTensor] = None
+
+
+class Layer:
+    """Base class: `layer(symbolic)` records a call; numerical work happens in forward/backward
+    which receive device tensors (batch axis first) and call the C-ABI."""
+
+    def __init__(self, name: Optional[str] = None, **kwargs):
+        self.name = name or K.unique_name(type(self).__name__)
+        self._nodes: List[Node] = []
+        self._built = False
+        self.weights: List[K.Variable] = []
+        self.trainable = True
+
+    # -- graph construction --
+    def build(self, input_shape):
+        pass
+
+    def compute_output_shape(self, input_shape):
+        return input_shape
+
+    def __call__(self, inputs):
+        ins = list(inputs) if isinstance(inputs, (list, tuple)) else [inputs]
+        if not all(isinstance(t, KTensor) for t in ins):
+            raise TypeError("layers are called on symbolic tensors; run data through a Model")
+        shapes = [t.shape for t in ins]
+        in_shape = shapes if isinstance(inputs, (list, tuple)) else shapes[0]
+        if not self._built:
+            self.build(in_shape)
+            self._built = True
+        node = Node(self, ins)
+        node.output = KTensor(self.compute_output_shape(in_shape), node)
+        self._nodes.append(node)
+        return node.output
+
+    @property
+    def output(self) -> KTensor:
+        if len(self._nodes) != 1:
+            raise AttributeError("layer %s has %d inbound nodes; .output is ambiguous" % (self.name, len(self._nodes)))
+        return self._nodes[0].output
+
+    @property
+    def input(self):
+        if len(self._nodes) != 1:
+            raise AttributeError("layer %s has %d inbound nodes; .input is ambiguous" % (self.name, len(self._nodes)))
+        ins = self._nodes[0].inputs
+        return ins[0] if len(ins) == 1 else ins
+
+    @property
+    def trainable_weights(self) -> List[K.Variable]:
+        return [v for v in self.weights if v.trainable] if self.trainable else []
+
+    def add_weight(self, kind: str, value: np.ndarray) -> K.Variable:
+        v = K.Variable("%s/%s" % (self.name, kind), value)
+        self.weights.append(v)
+        return v
+
+    def get_config(self):
+        return {"name": self.name}
+
+    # -- execution (device tensors) --
+    def forward(self, xs: List[torch.Tensor], save: bool):
+        """returns (y, saved)"""
+        raise NotImplementedError
+
+    def backward(self, saved, dy: torch.Tensor, need: List[bool], existing: List[Optional[torch.Tensor]],
+                 wgrad: bool):
+        """returns a list with, per input, None or (tensor, owned)"""
+        raise NotImplementedError
+
+
+class InputLayer(Layer):
+    def __init__(self, shape, name=None):
+        super().__init__(name=name or K.unique_name("Input"))
+        self.shape = tuple(shape)
+        node = Node(self, [])
+        node.output = KTensor((None,) + self.shape, node)
+        self._nodes.append(node)
+        self._built = True
+
+
+def Input(shape, name=None) -> KTensor:
+    """keras.layers.Input: returns the symbolic tensor of a new input layer."""
+    return InputLayer(shape, name=name).output
+
+
+# --------------------------------------------------------------------------------------------
+class _Op:
+    """One step of a model's execution plan: a node, optionally fused with the activation node
+    that consumes it."""
+
+    def __init__(self, node: Node, act_node: Optional[Node] = None):
+        self.node = node
+        self.act_node = act_node
+        self.inputs = node.inputs
+        self.output = act_node.output if act_node is not None else node.output
+
+
+class Model:
+    """keras.Model(inputs, outputs) for single-input single-output graphs."""
+
+    def __init__(self, inputs: KTensor, outputs: KTensor, name: Optional[str] = None):
+        if isinstance(inputs, (list, tuple)) or isinstance(outputs, (list, tuple)):
+            raise ValueError("single input / single output only")
+        self.name = name or K.unique_name("Model")
+        self.input = inputs
+        self.output = outputs
+        self._map_graph()
+        self._grad_flat: Optional[torch.Tensor] = None
+        self._grad_layout: Optional[List[Tuple[K.Variable, int, int]]] = None
+
+    # -- structure --
+    def _map_graph(self):
+        order: List[Node] = []
+        seen = set()
+        layer_index: Dict[int, int] = {}
+
+        def visit(t: KTensor):
+            node = t.node
+            if id(node) in seen:
+                return
+            seen.add(id(node))
+            for it in node.inputs:
+                visit(it)
+            if id(node.layer) not in layer_index:
+                layer_index[id(node.layer)] = len(layer_index)
+            order.append(node)
+
+        import sys
+        old = sys.getrecursionlimit()
+        sys.setrecursionlimit(max(old, 10000))
+        try:
+            visit(self.output)
+        finally:
+            sys.setrecursionlimit(old)
+        if id(self.input.node) not in seen:
+            raise ValueError("model output does not depend on its input")
+        self._nodes = order  # topological (inputs first)
+
+        # Keras orders `.layers` by decreasing depth (distance to the output), ties by traversal.
+        depth: Dict[int, int] = {}
+        ldepth: Dict[int, int] = {}
+        for node in reversed(order):
+            d = max(depth.get(id(node), 0), ldepth.get(id(node.layer), 0))
+            depth[id(node)] = d
+            ldepth[id(node.layer)] = d
+            for it in node.inputs:
+                depth[id(it.node)] = max(depth.get(id(it.node), 0), d + 1)
+        layers = {}
+        for node in order:
+            layers[id(node.layer)] = node.layer
+        maxd = max(ldepth.values()) if ldepth else 0
+        ldepth[id(self.input.node.layer)] = maxd
+        self.layers: List[Layer] = sorted(layers.values(),
+                                          key=lambda l: (-ldepth[id(l)], layer_index[id(l)]))
+
+        # execution plan with conv/dense + activation fusion
+        consumers: Dict[int, List[Node]] = {}
+        for node in order:
+            for it in node.inputs:
+                consumers.setdefault(id(it), []).append(node)
+        plan: List[_Op] = []
+        fused = set()
+        for node in order:
+            if isinstance(node.layer, InputLayer) or id(node) in fused:
+                continue
+            act = None
+            if getattr(node.layer, "fusable_activation", False) and node.output is not self.output:
+                cons = consumers.get(id(node.output), [])
+                if len(cons) == 1 and getattr(cons[0].layer, "is_soft_rectifier", False):
+                    act = cons[0]
+                    fused.add(id(act))
+            plan.append(_Op(node, act))
+        self._plan = plan
+        last_use: Dict[int, int] = {}
+        for i, op in enumerate(plan):
+            for it in op.inputs:
+                last_use[id(it)] = i
+        self._last_use = last_use
+
+    @property
+    def output_shape(self):
+        return self.output.shape
+
+    @property
+    def input_shape(self):
+        return self.input.shape
+
+    @property
+    def trainable_variables(self) -> List[K.Variable]:
+        out, seen = [], set()
+        for l in self.layers:
+            for v in l.trainable_weights:
+                if id(v) not in seen:
+                    seen.add(id(v))
+                    out.append(v)
+        return out
+
+    @property
+    def trainable_weights(self):
+        return self.trainable_variables
+
+    def count_params(self) -> int:
+        return sum(v.size for v in self.trainable_variables)
+
+    def get_layer(self, name):
+        for l in self.layers:
+            if l.name == name:
+                return l
+        raise KeyError(name)
+
+    # -- data plumbing --
+    def _to_device(self, x) -> torch.Tensor:
+        if isinstance(x, torch.Tensor):
+            t = x
+        else:
+            t = torch.from_numpy(np.ascontiguousarray(x, dtype=np.float32))
+        t = t.to(device=K.device(), dtype=torch.float32).contiguous()
+        if tuple(t.shape[1:]) != tuple(self.input.shape[1:]):
+            raise ValueError("input shape %s does not match the model input %s" % (tuple(t.shape), self.input.shape))
+        return t
+
+    # -- execution --
+    def forward(self, x, save: bool = False):
+        """Run the plan.  Returns (y, tape); tape is None unless save=True."""
+        x = self._to_device(x)
+        vals: Dict[int, torch.Tensor] = {id(self.input): x}
+        tape = [] if save else None
+        for i, op in enumerate(self._plan):
+            xs = [vals[id(t)] for t in op.inputs]
+            if op.act_node is not None:
+                y, saved = op.node.layer.forward(xs, save, act_alpha=op.act_node.layer.alpha_value)
+            else:
+                y, saved = op.node.layer.forward(xs, save)
+            vals[id(op.output)] = y
+            if save:
+                tape.append(saved)
+            for t in op.inputs:
+                if self._last_use.get(id(t)) == i and t is not self.output:
+                    vals.pop(id(t), None)
+        return vals[id(self.output)], tape
+
+    def __call__(self, x, training: bool = False):
+        if isinstance(x, KTensor):
+            raise TypeError("nested models are not supported")
+        y, _ = self.forward(x, save=False)
+        return y
+
+    def predict(self, x, batch_size: Optional[int] = None):
+        x = np.asarray(x, dtype=np.float32) if not isinstance(x, torch.Tensor) else x
+        n = x.shape[0]
+        bs = batch_size or 32
+        outs = []
+        for i in range(0, n, bs):
+            outs.append(self(x[i:i + bs]).cpu().numpy())
+        return np.concatenate(outs, axis=0)
+
+    def bind_grads(self) -> torch.Tensor:
+        """Point every trainable variable's `.grad` at its slice of this model's flat gradient
+        buffer (allocated once) and return the flat buffer."""
+        if self._grad_flat is None:
+            layout, off = [], 0
+            for v in self.trainable_variables:
+                n = v.size
+                layout.append((v, off, n))
+                off += (n + 3) & ~3           # keep every slice 16-byte aligned
+            self._grad_layout = layout
+            self._grad_flat = K.zeros((max(off, 4),))
+        for v, off, n in self._grad_layout:
+            v.grad = self._grad_flat[off:off + n]
+        return self._grad_flat
+
+    def grad_layout(self):
+        if self._grad_layout is None:
+            self.bind_grads()
+        return self._grad_layout
+
+    def backward(self, tape, dy: torch.Tensor, need_input_grad: bool = False, need_weight_grads: bool = True):
+        """Reverse sweep.  Weight gradients are ADDED into the variables' bound `.grad` views.
+        Returns the gradient w.r.t. the model input (or None)."""
+        grads: Dict[int, Tuple[torch.Tensor, bool]] = {id(self.output): (dy, False)}
+        for i in range(len(self._plan) - 1, -1, -1):
+            op = self._plan[i]
+            g = grads.pop(id(op.output), None)
+            if g is None:
+                continue
+            need = [(t is not self.input) or need_input_grad for t in op.inputs]
+            existing: List[Optional[torch.Tensor]] = []
+            pending = []
+            for t in op.inputs:
+                e = grads.get(id(t))
+                if e is not None and not e[1]:
+                    pending.append(e[0])      # aliased buffer: never accumulate into it
+                    existing.append(None)
+                else:
+                    pending.append(None)
+                    existing.append(e[0] if e is not None else None)
+            res = op.node.layer.backward(tape[i], g[0], need, existing, need_weight_grads)
+            tape[i] = None
+            for t, r, pend in zip(op.inputs, res, pending):
+                if r is None:
+                    continue
+                if pend is not None:
+                    out = K.empty(r[0].shape)
+                    ops.add_n([pend, r[0]], out)
+                    grads[id(t)] = (out, True)
+                else:
+                    grads[id(t)] = r
+        gi = grads.get(id(self.input))
+        return gi[0] if gi is not None else None
+
+    # -- persistence (numpy archive; the reference's .h5 path needs h5py/Keras) --
+    def get_weights_dict(self) -> Dict[str, np.ndarray]:
+        out = {}
+        for l in self.layers:
+            for v in l.weights:
+                out[v.name] = v.numpy()
+        return out
+
+    def set_weights_dict(self, weights: Dict[str, np.ndarray], strict: bool = True):
+        for l in self.layers:
+            for v in l.weights:
+                if v.name in weights:
+                    v.assign(np.asarray(weights[v.name]).reshape(v.shape))
+                elif strict:
+                    raise KeyError("no value for %s" % v.name)
+
+    def save(self, path: str):
+        np.savez(path, **{k.replace("/", "|"): v for k, v in self.get_weights_dict().items()})
+
+    def load_weights(self, path: str):
+        with np.load(path if path.endswith(".npz") else path + ".npz") as f:
+            self.set_weights_dict({k.replace("|", "/"): f[k] for k in f.files})

@@ -1,0 +1,422 @@
+"""Keras-equivalent layer objects used by trainer/models.py, backed by the libmgx kernels.
+
+Layouts follow Keras: NHWC activations; Conv2D kernel (kh,kw,Cin,Cout); Conv2DTranspose kernel
+(kh,kw,Cout,Cin); Dense kernel (in,out) applied to the last axis; LayerNormalization gamma/beta
+over the normalised axes.  Every contraction is expressed as one mgx_conv_desc (see
+include/mgx.h): forward, data-gradient and weight-gradient differ only in the descriptor.
+"""
+from __future__ import annotations
+
+import math
+import zlib
+from typing import List, Optional
+
+import numpy as np
+import torch
+
+from . import backend as K
+from . import ops
+from .graph import Layer
+
+_init_seed = [12345]
+
+
+def set_init_seed(seed: int):
+    """Seed of the (numpy) weight initialisers; TF's own RNG streams cannot be reproduced."""
+    _init_seed[0] = int(seed)
+
+
+def _rng(name: str):
+    return np.random.default_rng((_init_seed[0] * 1000003 + zlib.crc32(name.encode())) % (2 ** 63))
+
+
+def _fans(shape):
+    if len(shape) == 2:
+        return shape[0], shape[1]
+    rfs = int(np.prod(shape[:-2]))
+    return shape[-2] * rfs, shape[-1] * rfs
+
+
+def initial_value(initializer: str, shape, name: str) -> np.ndarray:
+    """he_normal (truncated normal, stddev sqrt(2/fan_in)/0.8796) and glorot_uniform as Keras
+    defines them (models.py:256 etc. pass 'he_normal'; Dense uses the glorot default)."""
+    fan_in, fan_out = _fans(shape)
+    rng = _rng(name)
+    if initializer == "he_normal":
+        std = math.sqrt(2.0 / max(1.0, fan_in)) / 0.87962566103423978
+        v = rng.standard_normal(shape)
+        bad = np.abs(v) > 2.0
+        while bad.any():
+            v[bad] = rng.standard_normal(int(bad.sum()))
+            bad = np.abs(v) > 2.0
+        return (v * std).astype(np.float32)
+    if initializer == "glorot_uniform":
+        lim = math.sqrt(6.0 / max(1.0, fan_in + fan_out))
+        return rng.uniform(-lim, lim, shape).astype(np.float32)
+    if initializer == "zeros":
+        return np.zeros(shape, dtype=np.float32)
+    if initializer == "ones":
+        return np.ones(shape, dtype=np.float32)
+    raise ValueError("unknown initializer %r" % (initializer,))
+
+
+def _pair(v):
+    return (int(v), int(v)) if isinstance(v, int) else (int(v[0]), int(v[1]))
+
+
+class _Contraction(Layer):
+    """Shared machinery of Conv2D / Conv2DTranspose / Dense: descriptor caches, the fused
+    tanh(x)+x/alpha epilogue and the two gradient calls."""
+    fusable_activation = True
+
+    def __init__(self, **kw):
+        super().__init__(**kw)
+        self._descs = {}
+
+    def _fwd_desc(self, n, h, w):
+        raise NotImplementedError
+
+    def _dgrad_desc(self, n, h, w):
+        raise NotImplementedError
+
+    def _out_hw(self, h, w):
+        raise NotImplementedError
+
+    def _desc(self, kind, n, h, w):
+        key = (kind, n, h, w)
+        d = self._descs.get(key)
+        if d is None:
+            d = self._fwd_desc(n, h, w) if kind == "f" else self._dgrad_desc(n, h, w)
+            self._descs[key] = d
+        return d
+
+    def forward(self, xs, save, act_alpha: float = 0.0):
+        x = xs[0]
+        n, h, w, _ = x.shape
+        ho, wo = self._out_hw(h, w)
+        y = K.empty((n, ho, wo, self.filters))
+        dact = K.empty(y.shape) if (save and act_alpha > 0.0) else None
+        ops.conv_gemm(self._desc("f", n, h, w), x, self.kernel.value(), self.bias.value(), y,
+                      dact=dact, act_alpha=act_alpha)
+        return y, ((x, dact) if save else None)
+
+    def backward(self, saved, dy, need, existing, wgrad):
+        x, dact = saved
+        n, h, w, _ = x.shape
+        if wgrad and self.trainable:
+            if self.kernel.grad is None or self.bias.grad is None:
+                raise RuntimeError("gradient buffers of %s are not bound" % self.name)
+            ops.conv_wgrad(self._desc("f", n, h, w), x, dy, self.kernel.grad, self.bias.grad, dymul=dact)
+        if not need[0]:
+            return [None]
+        dx = existing[0] if existing[0] is not None else K.empty(x.shape)
+        ops.conv_gemm(self._desc("d", n, h, w), dy, self.kernel.value(), None, dx, xmul=dact,
+                      accumulate=existing[0] is not None)
+        return [(dx, True)]
+
+
+class Conv2D(_Contraction):
+    def __init__(self, filters, kernel_size, strides=(1, 1), padding="valid", kernel_initializer="glorot_uniform",
+                 **kw):
+        super().__init__(**kw)
+        self.filters = int(filters)
+        self.kernel_size = _pair(kernel_size)
+        self.strides = _pair(strides)
+        self.padding = padding
+        self.kernel_initializer = kernel_initializer
+        if padding == "same" and self.strides != (1, 1):
+            raise NotImplementedError("'same' padding is implemented for stride 1 only (all the reference uses)")
+        if padding == "valid" and self.strides != self.kernel_size and self.kernel_size != (1, 1):
+            raise NotImplementedError("'valid' convolutions must have kernel == stride")
+
+    def build(self, input_shape):
+        cin = input_shape[-1]
+        kh, kw = self.kernel_size
+        self.cin = cin
+        self.kernel = self.add_weight("kernel", initial_value(self.kernel_initializer, (kh, kw, cin, self.filters),
+                                                              self.name + "/kernel"))
+        self.bias = self.add_weight("bias", np.zeros((self.filters,), dtype=np.float32))
+
+    def _out_hw(self, h, w):
+        if self.padding == "same":
+            return h, w
+        kh, kw = self.kernel_size
+        sh, sw = self.strides
+        return (h - kh) // sh + 1, (w - kw) // sw + 1
+
+    def compute_output_shape(self, s):
+        ho, wo = self._out_hw(s[1], s[2])
+        return (s[0], ho, wo, self.filters)
+
+    def _fwd_desc(self, n, h, w):
+        kh, kw = self.kernel_size
+        sh, sw = self.strides
+        ho, wo = self._out_hw(h, w)
+        pt, pl = ((kh - 1) // 2, (kw - 1) // 2) if self.padding == "same" else (0, 0)
+        return ops.make_conv_desc(nimg=n, hin=h, win=w, cin=self.cin, hout=ho, wout=wo, kh=kh, kw=kw, sh=sh, sw=sw,
+                                  pt=pt, pl=pl, ngemm=self.filters, cout=self.filters, wsk=self.filters, wsn=1,
+                                  wtap=self.cin * self.filters, nbias=self.filters)
+
+    def _dgrad_desc(self, n, h, w):
+        kh, kw = self.kernel_size
+        sh, sw = self.strides
+        ho, wo = self._out_hw(h, w)
+        if (sh, sw) == (1, 1):
+            # dX[p] = sum_tap dY[p - tap + pad] W[tap]^T : a 'same' gather with flipped taps
+            pt, pl = ((kh - 1) // 2, (kw - 1) // 2) if self.padding == "same" else (0, 0)
+            return ops.make_conv_desc(nimg=n, hin=ho, win=wo, cin=self.filters, hout=h, wout=w, kh=kh, kw=kw,
+                                      pt=kh - 1 - pt, pl=kw - 1 - pl, flip=1, ngemm=self.cin, cout=self.cin,
+                                      wsk=1, wsn=self.filters, wtap=self.cin * self.filters)
+        # kernel == stride: every input pixel belongs to exactly one window -> 1x1 GEMM over
+        # output pixels with a depth-to-space store of the (a,b,ci) columns
+        if h != ho * kh or w != wo * kw:
+            raise NotImplementedError("strided conv input must be a multiple of the kernel")
+        return ops.make_conv_desc(nimg=n, hin=ho, win=wo, cin=self.filters, hout=ho, wout=wo,
+                                  ngemm=kh * kw * self.cin, dkh=kh, dkw=kw, cout=self.cin, wsk=1, wsn=self.filters)
+
+
+class Conv2DTranspose(_Contraction):
+    def __init__(self, filters, kernel_size, strides=(1, 1), padding="valid", kernel_initializer="glorot_uniform",
+                 **kw):
+        super().__init__(**kw)
+        self.filters = int(filters)
+        self.kernel_size = _pair(kernel_size)
+        self.strides = _pair(strides)
+        self.kernel_initializer = kernel_initializer
+        if self.kernel_size != self.strides or padding != "valid":
+            raise NotImplementedError("Conv2DTranspose needs kernel == stride and 'valid' (all the reference uses)")
+
+    def build(self, input_shape):
+        cin = input_shape[-1]
+        kh, kw = self.kernel_size
+        self.cin = cin
+        self.kernel = self.add_weight("kernel", initial_value(self.kernel_initializer, (kh, kw, self.filters, cin),
+                                                              self.name + "/kernel"))
+        self.bias = self.add_weight("bias", np.zeros((self.filters,), dtype=np.float32))
+
+    def _out_hw(self, h, w):
+        return h * self.kernel_size[0], w * self.kernel_size[1]
+
+    def compute_output_shape(self, s):
+        return (s[0], s[1] * self.kernel_size[0], s[2] * self.kernel_size[1], self.filters)
+
+    def _fwd_desc(self, n, h, w):
+        kh, kw = self.kernel_size
+        return ops.make_conv_desc(nimg=n, hin=h, win=w, cin=self.cin, hout=h, wout=w,
+                                  ngemm=kh * kw * self.filters, dkh=kh, dkw=kw, cout=self.filters,
+                                  wsk=1, wsn=self.cin, nbias=self.filters)
+
+    def _dgrad_desc(self, n, h, w):
+        kh, kw = self.kernel_size
+        return ops.make_conv_desc(nimg=n, hin=h * kh, win=w * kw, cin=self.filters, hout=h, wout=w, kh=kh, kw=kw,
+                                  sh=kh, sw=kw, ngemm=self.cin, cout=self.cin, wsk=self.cin, wsn=1,
+                                  wtap=self.filters * self.cin)
+
+
+class Dense(_Contraction):
+    """Dense on the last axis.  Rank-4 inputs run as a 1x1 contraction; the rank-2 input with one
+    unit (Flatten -> Dense(1), models.py:339-340) runs as a wavefront-reduction GEMV."""
+
+    def __init__(self, units, kernel_initializer="glorot_uniform", **kw):
+        super().__init__(**kw)
+        self.filters = int(units)
+        self.units = int(units)
+        self.kernel_initializer = kernel_initializer
+
+    def build(self, input_shape):
+        cin = input_shape[-1]
+        self.cin = cin
+        self.kernel = self.add_weight("kernel", initial_value(self.kernel_initializer, (cin, self.units),
+                                                              self.name + "/kernel"))
+        self.bias = self.add_weight("bias", np.zeros((self.units,), dtype=np.float32))
+
+    def _out_hw(self, h, w):
+        return h, w
+
+    def compute_output_shape(self, s):
+        return tuple(s[:-1]) + (self.units,)
+
+    def _fwd_desc(self, n, h, w):
+        return ops.make_conv_desc(nimg=n, hin=h, win=w, cin=self.cin, hout=h, wout=w, ngemm=self.units,
+                                  cout=self.units, wsk=self.units, wsn=1, nbias=self.units)
+
+    def _dgrad_desc(self, n, h, w):
+        return ops.make_conv_desc(nimg=n, hin=h, win=w, cin=self.units, hout=h, wout=w, ngemm=self.cin,
+                                  cout=self.cin, wsk=1, wsn=self.units)
+
+    def forward(self, xs, save, act_alpha: float = 0.0):
+        x = xs[0]
+        if x.dim() == 4:
+            return super().forward(xs, save, act_alpha)
+        n, e = x.shape
+        if self.units == 1:
+            y = K.empty((n, 1))
+            ops.dense1_fwd(x, self.kernel.value(), self.bias.value(), y, n, e)
+            if act_alpha > 0.0:
+                pre = y
+                y = K.empty((n, 1))
+                ops.softrect_fwd(pre, y, act_alpha)
+                return y, ((x, pre, act_alpha) if save else None)
+            return y, ((x, None, 0.0) if save else None)
+        y4, saved = super().forward([x.view(n, 1, 1, e)], save, act_alpha)
+        return y4.view(n, self.units), saved
+
+    def backward(self, saved, dy, need, existing, wgrad):
+        if len(saved) == 2:
+            x, _ = saved
+            if x.dim() == 4 and dy.dim() == 4:
+                return super().backward(saved, dy, need, existing, wgrad)
+            n = x.shape[0]
+            res = super().backward(saved, dy.view(n, 1, 1, self.units), need,
+                                   [e.view(x.shape) if e is not None else None for e in existing], wgrad)
+            return [None if r is None else (r[0].view(n, -1), r[1]) for r in res]
+        x, pre, act_alpha = saved
+        n, e = x.shape
+        if pre is not None:
+            dpre = K.empty((n, 1))
+            ops.softrect_bwd(dy, pre, dpre, False, act_alpha)
+            dy = dpre
+        do_w = wgrad and self.trainable
+        dx = None
+        if need[0]:
+            if existing[0] is not None:
+                raise NotImplementedError("Dense(1) input gradient cannot accumulate")
+            dx = K.empty((n, e))
+        if do_w or dx is not None:
+            ops.dense1_bwd(dy, x, self.kernel.value(), dx, self.kernel.grad if do_w else None,
+                           self.bias.grad if do_w else None, n, e)
+        return [(dx, True) if dx is not None else None]
+
+
+class UpSampling2D(Layer):
+    def __init__(self, size=(2, 2), **kw):
+        super().__init__(**kw)
+        if _pair(size) != (2, 2):
+            raise NotImplementedError("only the default size (2,2) is used by the reference")
+
+    def compute_output_shape(self, s):
+        return (s[0], s[1] * 2, s[2] * 2, s[3])
+
+    def forward(self, xs, save):
+        x = xs[0]
+        n, h, w, c = x.shape
+        y = K.empty((n, 2 * h, 2 * w, c))
+        ops.upsample2x_fwd(x, y, n, h, w, c)
+        return y, (tuple(x.shape) if save else None)
+
+    def backward(self, saved, dy, need, existing, wgrad):
+        if not need[0]:
+            return [None]
+        n, h, w, c = saved
+        dx = existing[0] if existing[0] is not None else K.empty(saved)
+        ops.upsample2x_bwd(dy, dx, n, h, w, c, existing[0] is not None)
+        return [(dx, True)]
+
+
+class AveragePooling2D(Layer):
+    def __init__(self, pool_size=(2, 2), **kw):
+        super().__init__(**kw)
+        if _pair(pool_size) != (2, 2):
+            raise NotImplementedError("only the default pool size (2,2) is used by the reference")
+
+    def compute_output_shape(self, s):
+        return (s[0], s[1] // 2, s[2] // 2, s[3])
+
+    def forward(self, xs, save):
+        x = xs[0]
+        n, h, w, c = x.shape
+        y = K.empty((n, h // 2, w // 2, c))
+        ops.avgpool2x_fwd(x, y, n, h, w, c)
+        return y, (tuple(x.shape) if save else None)
+
+    def backward(self, saved, dy, need, existing, wgrad):
+        if not need[0]:
+            return [None]
+        n, h, w, c = saved
+        dx = existing[0] if existing[0] is not None else K.empty(saved)
+        ops.avgpool2x_bwd(dy, dx, n, h, w, c, existing[0] is not None)
+        return [(dx, True)]
+
+
+class Add(Layer):
+    def compute_output_shape(self, shapes):
+        return shapes[0]
+
+    def _merge_function(self, inputs):
+        y = K.empty(inputs[0].shape)
+        ops.add_n(inputs, y)
+        return y
+
+    def forward(self, xs, save):
+        return self._merge_function(xs), (len(xs) if save else None)
+
+    def backward(self, saved, dy, need, existing, wgrad):
+        out = []
+        for nd, ex in zip(need, existing):
+            if not nd:
+                out.append(None)
+            elif ex is not None:
+                ops.add_inplace(ex, dy)
+                out.append((ex, True))
+            else:
+                out.append((dy, False))      # alias: the executor never accumulates into it
+        return out
+
+
+class Flatten(Layer):
+    def compute_output_shape(self, s):
+        n = 1
+        for d in s[1:]:
+            n *= d
+        return (s[0], n)
+
+    def forward(self, xs, save):
+        x = xs[0]
+        return x.view(x.shape[0], -1), (tuple(x.shape) if save else None)
+
+    def backward(self, saved, dy, need, existing, wgrad):
+        if not need[0]:
+            return [None]
+        g = dy.view(saved)
+        if existing[0] is not None:
+            ops.add_inplace(existing[0], g)
+            return [(existing[0], True)]
+        return [(g, True)]
+
+
+class LayerNormalization(Layer):
+    """LayerNormalization(axis=[1,2,3]) with Keras defaults (epsilon 1e-3, gamma=1, beta=0)."""
+
+    def __init__(self, axis=-1, epsilon=1e-3, **kw):
+        super().__init__(**kw)
+        ax = list(axis) if isinstance(axis, (list, tuple)) else [axis]
+        if sorted(ax) != [1, 2, 3]:
+            raise NotImplementedError("only axis=[1,2,3] is used by the reference")
+        self.epsilon = float(epsilon)
+
+    def build(self, input_shape):
+        shp = tuple(input_shape[1:])
+        self.gamma = self.add_weight("gamma", np.ones(shp, dtype=np.float32))
+        self.beta = self.add_weight("beta", np.zeros(shp, dtype=np.float32))
+
+    def forward(self, xs, save):
+        x = xs[0]
+        n = x.shape[0]
+        e = x.numel() // n
+        y = K.empty(x.shape)
+        stats = K.empty((n, 2))
+        ops.layernorm_fwd(x, self.gamma.value(), self.beta.value(), y, stats, n, e, self.epsilon)
+        return y, ((x, stats) if save else None)
+
+    def backward(self, saved, dy, need, existing, wgrad):
+        x, stats = saved
+        n = x.shape[0]
+        e = x.numel() // n
+        do_w = wgrad and self.trainable
+        dx = None
+        if need[0]:
+            dx = existing[0] if existing[0] is not None else K.empty(x.shape)
+        if dx is not None or do_w:
+            ops.layernorm_bwd(dy, x, self.gamma.value(), stats, dx, existing[0] is not None,
+                              self.gamma.grad if do_w else None, self.beta.grad if do_w else None, n, e)
+        return [(dx, True) if dx is not None else None]

@@ -1,0 +1,522 @@
+"""Construction API and training step of the progressive GAN, mirroring trainer/models.py so that
+trainer/task.py-style drivers can switch to this package unchanged:
+
+    define_discriminator, add_discriminator_block, define_generator, add_generator_block,
+    define_composite, WGAN, WeightedSum, MinibatchStdDev, SoftRectifier, StaticOptTanh,
+    discriminator_loss, generator_loss, Adam, GANMonitor
+
+Every numerical operation runs in a hand-written gfx950 kernel behind the C-ABI of include/mgx.h;
+this file only wires layer objects and sequences kernel launches.
+"""
+from __future__ import annotations
+
+import math
+from typing import Dict, List, Optional, Sequence
+
+import numpy as np
+import torch
+
+from . import backend
+from . import backend as K
+from . import ops
+from .graph import Input, Layer, Model
+from .layers import (Add, AveragePooling2D, Conv2D, Conv2DTranspose, Dense, Flatten, LayerNormalization,
+                     UpSampling2D)
+
+# --------------------------------------------------------------------------------------------
+# custom layers of trainer/models.py
+# --------------------------------------------------------------------------------------------
+
+
+class WeightedSum(Add):
+    """Fade-in blend ((1-a)*x0 + a*x1), trainer/models.py:23-35.  As in the reference the blend
+    factor is a variable created with backend.variable, hence trainable unless
+    `alpha.trainable` is cleared (WGAN(trainable_alpha=False))."""
+
+    def __init__(self, alpha=0.0, **kwargs):
+        super().__init__(**kwargs)
+        self.alpha = backend.Variable(self.name + "/alpha", np.asarray(alpha, dtype=np.float32))
+        self.weights.append(self.alpha)
+
+    def _merge_function(self, inputs):
+        assert len(inputs) == 2                                   # models.py:32
+        y = K.empty(inputs[0].shape)
+        ops.weighted_sum_fwd(inputs[0], inputs[1], self.alpha.value(), y)
+        return y
+
+    def forward(self, xs, save):
+        return self._merge_function(xs), ((xs[0], xs[1]) if save else None)
+
+    def backward(self, saved, dy, need, existing, wgrad):
+        a, b = saved
+        da = db = None
+        if need[0]:
+            da = existing[0] if existing[0] is not None else K.empty(a.shape)
+        if need[1]:
+            db = existing[1] if existing[1] is not None else K.empty(b.shape)
+        dalpha = self.alpha.grad if (wgrad and self.trainable and self.alpha.trainable) else None
+        if dalpha is None and wgrad and self.trainable and self.alpha.trainable:
+            raise RuntimeError("gradient buffer of %s is not bound" % self.alpha.name)
+        ops.weighted_sum_bwd(dy, a, b, self.alpha.value(), da, existing[0] is not None, db,
+                             existing[1] is not None, dalpha)
+        return [(da, True) if da is not None else None, (db, True) if db is not None else None]
+
+    def get_config(self):
+        cfg = super().get_config()
+        cfg.update({"alpha": float(self.alpha.numpy())})
+        return cfg
+
+
+class MinibatchStdDev(Layer):
+    """trainer/models.py:162-192.  The data is NHWC although the reference's comments assume
+    NCHW, so the group statistic becomes an extra ROW: (N,H,W,C) -> (N,H+1,W,C)."""
+
+    def compute_output_shape(self, s):
+        return (s[0], s[1] + 1, s[2], s[3])
+
+    def forward(self, xs, save):
+        x = xs[0]
+        n, h, w, c = x.shape
+        g = min(4, n)
+        if n % g:
+            raise ValueError("MinibatchStdDev: batch %d is not divisible by the group size %d" % (n, g))
+        y = K.empty((n, h + 1, w, c))
+        stat = K.empty((n // g,))
+        ops.mbstd_fwd(x, y, stat, n, h, w, c)
+        return y, (x if save else None)
+
+    def backward(self, saved, dy, need, existing, wgrad):
+        if not need[0]:
+            return [None]
+        x = saved
+        n, h, w, c = x.shape
+        dx = K.empty(x.shape)
+        ops.mbstd_bwd(dy, x, dx, n, h, w, c)
+        if existing[0] is not None:
+            ops.add_inplace(existing[0], dx)
+            return [(existing[0], True)]
+        return [(dx, True)]
+
+
+class _TanhPlusLinear(Layer):
+    is_soft_rectifier = True
+    alpha_value = 1.0
+
+    def forward(self, xs, save):
+        x = xs[0]
+        y = K.empty(x.shape)
+        ops.softrect_fwd(x, y, self.alpha_value)
+        return y, (x if save else None)
+
+    def backward(self, saved, dy, need, existing, wgrad):
+        if not need[0]:
+            return [None]
+        dx = existing[0] if existing[0] is not None else K.empty(saved.shape)
+        ops.softrect_bwd(dy, saved, dx, existing[0] is not None, self.alpha_value)
+        return [(dx, True)]
+
+
+class SoftRectifier(_TanhPlusLinear):
+    """tanh(x) + x/start_alpha, trainer/models.py:199-211."""
+
+    def __init__(self, start_alpha=20000.0, **kwargs):
+        super().__init__(**kwargs)
+        self.start_alpha = start_alpha
+        self.alpha_value = float(start_alpha)
+
+    def get_config(self):
+        cfg = super().get_config()
+        cfg.update({"start_alpha": self.start_alpha})
+        return cfg
+
+
+class StaticOptTanh(_TanhPlusLinear):
+    """tanh(x) + x/alpha, trainer/models.py:214-225."""
+
+    def __init__(self, alpha=1500.0, **kwargs):
+        super().__init__(**kwargs)
+        self.alpha = alpha
+        self.alpha_value = float(alpha)
+
+    def get_config(self):
+        cfg = super().get_config()
+        cfg.update({"alpha": self.alpha})
+        return cfg
+
+
+# --------------------------------------------------------------------------------------------
+# discriminator (trainer/models.py:229-354)
+# --------------------------------------------------------------------------------------------
+# (StaticOptTanh alpha, SoftRectifier alpha) keyed on the height of the model being grown
+_D_ALPHAS = {8: (60000.0, 40000.0), 16: (90000.0, 80000.0), 32: (120000.0, 120000.0),
+             64: (150000.0, 150000.0), 128: (200000.0, 11000.0), 256: (350000.0, 200000.0)}
+
+
+def _conv_act(t, filters, ksize, soft_alpha, strides=(1, 1), padding="same"):
+    t = Conv2D(filters, ksize, strides=strides, padding=padding, kernel_initializer="he_normal")(t)
+    return SoftRectifier(start_alpha=soft_alpha)(t)
+
+
+def _replay_tail(old_model, t, n_input_layers, alpha):
+    """Re-apply old_model.layers[n_input_layers:] to t, swapping the final StaticOptTanh for a
+    new one (models.py:284-288 / 299-303)."""
+    final = None
+    for layer in old_model.layers[n_input_layers:]:
+        if isinstance(layer, StaticOptTanh):
+            final = StaticOptTanh(alpha=alpha)(t)
+        else:
+            t = layer(t)
+    return final
+
+
+def add_discriminator_block(old_model, n_input_layers=3):
+    in_shape = list(old_model.input[0].shape)
+    alpha, soft_alpha = _D_ALPHAS.get(in_shape[-3], (40000.0, 20000.0))
+    in_image = Input(shape=(in_shape[-3] * 2, in_shape[-2] * 2, in_shape[-1]))
+    # new from-audio 1x1 conv, then three conv groups; the last conv of the third group halves
+    # the resolution (2x2 stride 2, 'valid'); a 1x1 conv restores 128 features
+    t = _conv_act(in_image, 128, (1, 1), soft_alpha)
+    for group in range(3):
+        t = _conv_act(t, 32, (3, 3), soft_alpha)
+        t = _conv_act(t, 32, (3, 3), soft_alpha)
+        if group < 2:
+            t = _conv_act(t, 32, (2, 2), soft_alpha)
+        else:
+            t = _conv_act(t, 32, (2, 2), soft_alpha, strides=(2, 2), padding="valid")
+    block_new = _conv_act(t, 128, (1, 1), soft_alpha)
+    straight = Model(in_image, _replay_tail(old_model, block_new, n_input_layers, alpha))
+    # fade-in twin: the old from-audio conv + activation on the average-pooled input, blended
+    downsample = AveragePooling2D()(in_image)
+    block_old = old_model.layers[2](old_model.layers[1](downsample))
+    blended = WeightedSum()([block_old, block_new])
+    fadein = Model(in_image, _replay_tail(old_model, blended, n_input_layers, alpha))
+    return [straight, fadein]
+
+
+def define_discriminator(n_blocks, input_shape=(4, 750, 2)):
+    in_image = Input(shape=input_shape)
+    t = Conv2D(128, (1, 1), padding="same", kernel_initializer="he_normal")(in_image)
+    t = SoftRectifier()(t)
+    for group in range(3):
+        for ksize in ((3, 3), (4, 4), (3, 3)):
+            t = Conv2D(32, ksize, padding="same", kernel_initializer="he_normal")(t)
+            t = SoftRectifier()(t)
+    t = MinibatchStdDev()(t)
+    t = Flatten()(t)
+    t = Dense(1)(t)
+    base = Model(in_image, StaticOptTanh(alpha=40000.0)(t))
+    model_list = [[base, base]]
+    for i in range(1, n_blocks):
+        model_list.append(add_discriminator_block(model_list[i - 1][0]))
+    return model_list
+
+
+# --------------------------------------------------------------------------------------------
+# generator (trainer/models.py:358-463)
+# --------------------------------------------------------------------------------------------
+def _g_tail(t):
+    for units in (256, 64, 8, 2):
+        t = Dense(units)(t)
+    return t
+
+
+def add_generator_block(old_model):
+    block_end = old_model.layers[-2].output          # last Dense(2), before its LayerNormalization
+    upsampling = UpSampling2D()(block_end)
+    featured = Conv2D(128, (2, 2), strides=(2, 2), padding="valid", kernel_initializer="he_normal")(upsampling)
+    branches = []
+    for _ in range(6):
+        g = Conv2DTranspose(16, (2, 1), strides=(2, 1), padding="valid", kernel_initializer="he_normal")(featured)
+        g = Dense(32)(g)
+        g = Conv2DTranspose(64, (1, 2), strides=(1, 2), padding="valid", kernel_initializer="he_normal")(g)
+        branches.append(Dense(128)(g))
+    for_sum_layer = _g_tail(Add()(branches))
+    model1 = Model(old_model.input, LayerNormalization(axis=[1, 2, 3])(for_sum_layer))
+    merged = WeightedSum()([upsampling, for_sum_layer])
+    model2 = Model(old_model.input, LayerNormalization(axis=[1, 2, 3])(merged))
+    return [model1, model2]
+
+
+def define_generator(n_blocks):
+    ly0 = Input(shape=(1, 100, 2))
+    featured = Conv2D(128, (1, 2), strides=(1, 2), padding="valid", kernel_initializer="he_normal")(ly0)
+    branches = []
+    for _ in range(4):
+        g = featured
+        for filters, ksize, units in ((4, (2, 1), 8), (16, (2, 1), 32), (64, (1, 15), 128)):
+            g = Conv2DTranspose(filters, ksize, strides=ksize, padding="valid", kernel_initializer="he_normal")(g)
+            g = Dense(units)(g)
+        branches.append(g)
+    out = LayerNormalization(axis=[1, 2, 3])(_g_tail(Add()(branches)))
+    model = Model(ly0, out)
+    model_list = [[model, model]]
+    for i in range(1, n_blocks):
+        model_list.append(add_generator_block(model_list[i - 1][0]))
+    return model_list
+
+
+# --------------------------------------------------------------------------------------------
+# losses (trainer/models.py:468-484).  Host-callable versions for (N,1) logit tensors; the
+# training step uses the same kernel to also emit d(loss)/d(logit).
+# --------------------------------------------------------------------------------------------
+def _loss(fake_logits, real_logits, mode):
+    fake = fake_logits if isinstance(fake_logits, torch.Tensor) else torch.as_tensor(np.asarray(fake_logits, np.float32))
+    real = real_logits if isinstance(real_logits, torch.Tensor) else torch.as_tensor(np.asarray(real_logits, np.float32))
+    fake = fake.to(K.device(), torch.float32).contiguous().view(-1)
+    real = real.to(K.device(), torch.float32).contiguous().view(-1)
+    sums, out4 = K.empty((2,)), K.empty((4,))
+    ops.logit_sums(fake, real, sums)
+    ops.wgan_loss(sums, fake.numel(), mode, out4, None, None, 0)
+    return out4[0]
+
+
+def discriminator_loss(fake_logits, real_logits):
+    return _loss(fake_logits, real_logits, 0)
+
+
+def generator_loss(fake_logits, real_logits):
+    return _loss(fake_logits, real_logits, 1)
+
+
+# --------------------------------------------------------------------------------------------
+# optimiser
+# --------------------------------------------------------------------------------------------
+class Adam:
+    """keras.optimizers.Adam as configured by define_composite (models.py:502-503): the update of
+    tf.keras OptimizerV2 (non-amsgrad) with beta_1 = 0, so the first moment equals the gradient.
+    One fused multi-tensor kernel updates every variable of a model."""
+
+    def __init__(self, lr=0.001, beta_1=0.9, beta_2=0.999, epsilon=1e-7, learning_rate=None):
+        self.lr = float(learning_rate if learning_rate is not None else lr)
+        self.beta_1, self.beta_2, self.epsilon = float(beta_1), float(beta_2), float(epsilon)
+        if self.beta_1 != 0.0:
+            raise NotImplementedError("the fused Adam kernel implements beta_1 = 0 (the reference's setting)")
+        self.iterations = 0
+        self._state = None
+
+    def _build(self, model: Model):
+        layout = model.grad_layout()
+        flat = model.bind_grads()
+        dev = flat.device
+        ptrs, ns, offs, blk_t, blk_s = [], [], [], [], []
+        for i, (v, off, n) in enumerate(layout):
+            ptrs.append(v.value().data_ptr()); ns.append(n); offs.append(off)
+            for start in range(0, n, 4096):
+                blk_t.append(i); blk_s.append(start)
+        self._state = dict(
+            model=model, v=torch.zeros_like(flat),
+            p=torch.tensor(ptrs, dtype=torch.int64, device=dev), n=torch.tensor(ns, dtype=torch.int64, device=dev),
+            off=torch.tensor(offs, dtype=torch.int64, device=dev),
+            blk_t=torch.tensor(blk_t, dtype=torch.int32, device=dev),
+            blk_s=torch.tensor(blk_s, dtype=torch.int64, device=dev), nblocks=len(blk_t))
+
+    def apply_model_gradients(self, model: Model):
+        """Adam.apply_gradients(zip(grads, model.trainable_variables)) for gradients held in the
+        model's flat gradient buffer."""
+        if self._state is None:
+            self._build(model)
+        st = self._state
+        if st["model"] is not model:
+            raise RuntimeError("an Adam instance is bound to the first model it updates")
+        self.iterations += 1
+        lr_t = self.lr * math.sqrt(1.0 - self.beta_2 ** self.iterations)
+        ops.adam_multi(st["p"], st["n"], st["off"], model.bind_grads(), st["v"], st["blk_t"], st["blk_s"],
+                       st["nblocks"], lr_t, self.beta_2, self.epsilon)
+
+    def second_moments(self) -> Dict[str, np.ndarray]:
+        if self._state is None:
+            return {}
+        v = self._state["v"].cpu().numpy()
+        return {var.name: v[off:off + n].reshape(var.shape).copy() for var, off, n in self._state["model"].grad_layout()}
+
+
+# --------------------------------------------------------------------------------------------
+# WGAN (trainer/models.py:42-158)
+# --------------------------------------------------------------------------------------------
+class History:
+    def __init__(self):
+        self.history: Dict[str, List[float]] = {}
+
+
+class WGAN:
+    def __init__(self, discriminator, generator, latent_dim, fade_in=False, discriminator_extra_steps=3,
+                 gp_weight=10.0, trainable_alpha=True):
+        self.discriminator = discriminator
+        self.generator = generator
+        self.latent_dim = latent_dim
+        self.d_steps = discriminator_extra_steps
+        self.gp_weight = gp_weight            # stored and never used, as in the reference
+        self.actual_step = 0
+        self.total_steps = 0
+        self.fade_in = fade_in
+        self.train_steps = None
+        self.dist = None                      # parallel.DataParallel when sharded over GPUs
+        self.last_losses = None
+        self._latents: List = []
+        self._rng: Optional[torch.Generator] = None
+        for model in (discriminator, generator):
+            for layer in model.layers:
+                if isinstance(layer, WeightedSum):
+                    layer.alpha.trainable = bool(trainable_alpha)
+
+    def compile(self, d_optimizer, g_optimizer, d_loss_fn=None, g_loss_fn=None):
+        self.d_optimizer = d_optimizer
+        self.g_optimizer = g_optimizer
+        self.d_loss_fn = d_loss_fn
+        self.g_loss_fn = g_loss_fn
+
+    def set_train_steps(self, size):
+        self.train_steps = size
+
+    # -- latent vectors: drawn on the device, or injected for parity runs --
+    def inject_latents(self, zs: Sequence):
+        """Queue latent batches; the next draws of train_step consume them in order (D step,
+        metric 0, G step, metric 1)."""
+        self._latents.extend(zs)
+
+    def seed(self, seed: int):
+        self._rng = torch.Generator(device=K.device())
+        self._rng.manual_seed(int(seed))
+
+    def _draw(self, n):
+        if self._latents:
+            z = self._latents.pop(0)
+            z = z if isinstance(z, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(z, dtype=np.float32))
+            return z.to(K.device(), torch.float32).contiguous()
+        return torch.randn((n,) + tuple(self.latent_dim), dtype=torch.float32, device=K.device(), generator=self._rng)
+
+    def _logit_stats(self, fake_logits, real_logits, mode, n_local, want_seeds):
+        """sums -> (all-reduce) -> loss/metrics kernel.  Returns (out4, dfake, dreal)."""
+        sums, out4 = K.empty((2,)), K.empty((4,))
+        ops.logit_sums(fake_logits.view(-1), real_logits.view(-1), sums)
+        n_global = n_local
+        if self.dist is not None:
+            self.dist.all_reduce(sums)
+            n_global = n_local * self.dist.world_size
+        dfake = K.empty((n_local, 1)) if want_seeds else None
+        dreal = K.empty((n_local, 1)) if (want_seeds and mode == 0) else None
+        ops.wgan_loss(sums, n_global, mode, out4, dfake, dreal, n_local if want_seeds else 0)
+        return out4, dfake, dreal
+
+    def train_step(self, real_images):
+        if self.fade_in:
+            if self.train_steps is None or self.train_steps < 2:
+                raise ValueError("fade-in needs set_train_steps(n) with n >= 2 (alpha = step/(n-1))")
+            alpha = self.actual_step / float(self.train_steps - 1)
+            for model in (self.discriminator, self.generator):
+                for layer in model.layers:
+                    if isinstance(layer, WeightedSum):
+                        backend.set_value(layer.alpha, alpha)
+        if isinstance(real_images, tuple):
+            real_images = real_images[0]
+        D, G = self.discriminator, self.generator
+        real = D._to_device(real_images)
+        n = real.shape[0]
+
+        # ---- discriminator update(s) ----
+        for _ in range(self.d_steps):
+            z = self._draw(n)
+            flat = D.bind_grads()
+            flat.zero_()
+            fake, _ = G.forward(z, save=False)
+            fake_logits, tape_f = D.forward(fake, save=True)
+            real_logits, tape_r = D.forward(real, save=True)
+            out_d, dfake, dreal = self._logit_stats(fake_logits, real_logits, 0, n, True)
+            D.backward(tape_f, dfake, need_input_grad=False)
+            D.backward(tape_r, dreal, need_input_grad=False)
+            del tape_f, tape_r, fake
+            if self.dist is not None:
+                self.dist.all_reduce(flat)
+            self.d_optimizer.apply_model_gradients(D)
+
+        # ---- metric block 0 ----
+        fake_logits = D(G(self._draw(n)))
+        real_logits = D(real)
+        m0, _, _ = self._logit_stats(fake_logits, real_logits, 0, n, False)
+
+        # ---- generator update ----
+        z = self._draw(n)
+        flat = G.bind_grads()
+        flat.zero_()
+        gen, tape_g = G.forward(z, save=True)
+        gen_logits, tape_d = D.forward(gen, save=True)
+        real_logits = D(real)
+        out_g, dgen_logits, _ = self._logit_stats(gen_logits, real_logits, 1, n, True)
+        dgen = D.backward(tape_d, dgen_logits, need_input_grad=True, need_weight_grads=False)
+        G.backward(tape_g, dgen, need_input_grad=False)
+        del tape_d, tape_g, gen, dgen
+        if self.dist is not None:
+            self.dist.all_reduce(flat)
+        self.g_optimizer.apply_model_gradients(G)
+
+        # ---- metric block 1 ----
+        fake_logits = D(G(self._draw(n)))
+        real_logits = D(real)
+        m1, _, _ = self._logit_stats(fake_logits, real_logits, 0, n, False)
+
+        self.actual_step += 1
+        self.last_losses = {"d_loss": out_d[0], "g_loss": out_g[0]}
+        return {"delta_0": m0[3], "cu_0": m0[1], "ci_0": m0[2], "delta_1": m1[3], "cu_1": m1[1], "ci_1": m1[2]}
+
+    def fit(self, x, batch_size=32, epochs=1, callbacks=None, shuffle=True, verbose=0):
+        """keras.Model.fit for this custom step: per epoch a fresh permutation, full passes in
+        batches, History holds the last batch's metrics of every epoch."""
+        callbacks = list(callbacks or [])
+        for cb in callbacks:
+            cb.model = self
+        hist = History()
+        n = x.shape[0]
+        rng = np.random.default_rng(0)
+        for epoch in range(epochs):
+            order = rng.permutation(n) if shuffle else np.arange(n)
+            logs = None
+            for i in range(0, n, batch_size):
+                idx = order[i:i + batch_size]
+                logs = self.train_step(x[idx])
+            logs = {k: float(v) for k, v in (logs or {}).items()}
+            for k, v in logs.items():
+                hist.history.setdefault(k, []).append(v)
+            if verbose:
+                print("epoch %d/%d " % (epoch + 1, epochs) + " ".join("%s=%.5f" % kv for kv in logs.items()))
+            for cb in callbacks:
+                cb.on_epoch_end(epoch, logs)
+        return hist
+
+
+def define_composite(discriminators, generators, latent_dim, trainable_alpha=True):
+    """One straight and one fade-in WGAN per stage, each compiled with its own pair of fresh Adam
+    optimisers (lr 5e-4, beta_1 0, beta_2 0.99, epsilon 10e-8) — trainer/models.py:488-524."""
+    model_list = []
+    for d_models, g_models in zip(discriminators, generators):
+        pair = []
+        for twin, fade in ((0, False), (1, True)):
+            gan = WGAN(discriminator=d_models[twin], generator=g_models[twin], latent_dim=latent_dim, fade_in=fade,
+                       discriminator_extra_steps=1, trainable_alpha=trainable_alpha)
+            gan.compile(d_optimizer=Adam(lr=0.0005, beta_1=0, beta_2=0.99, epsilon=10e-8),
+                        g_optimizer=Adam(lr=0.0005, beta_1=0, beta_2=0.99, epsilon=10e-8),
+                        g_loss_fn=generator_loss, d_loss_fn=discriminator_loss)
+            pair.append(gan)
+        model_list.append(pair)
+    return model_list
+
+
+class GANMonitor:
+    """Epoch-end hook in the spirit of trainer/models.py:528-551: for straight-through models it
+    draws `num_examples` batches of 10 clips from the generator (the inference call shape of
+    trainer/utils.py:103-104) and hands them to `sink(epoch, batch_index, audio)`.  The reference's
+    cloud upload, evaluator network and .h5 export are outside this package."""
+
+    def __init__(self, job_dir=None, evaluador=None, num_examples=20, latent_dim=(1, 100, 2), sink=None):
+        self.num_examples = num_examples
+        self.latent_dim = latent_dim
+        self.job_dir = job_dir
+        self.evaluador = evaluador
+        self.sink = sink
+        self.model = None
+
+    def on_epoch_end(self, epoch, logs=None):
+        if self.model is None or self.model.fade_in or self.sink is None:
+            return
+        for i in range(self.num_examples):
+            z = torch.randn((10,) + tuple(self.latent_dim), dtype=torch.float32, device=K.device())
+            self.sink(epoch, i, self.model.generator(z, training=False))

@@ -1,0 +1,230 @@
+"""Thin typed wrappers over the C-ABI: torch tensors in, device pointers out.  Every wrapper checks
+on the host that operand sizes match what the kernel and its grid assume before launching.
+"""
+from __future__ import annotations
+
+import ctypes as C
+from typing import List, Optional, Sequence
+
+import torch
+
+from . import _cabi
+from . import backend as K
+from ._cabi import ConvDesc, MgxError, check
+
+
+def _p(t: Optional[torch.Tensor]):
+    if t is None:
+        return None
+    if t.dtype != torch.float32 or not t.is_cuda or not t.is_contiguous():
+        raise MgxError("operand must be a contiguous float32 device tensor")
+    return t.data_ptr()
+
+
+def _lib():
+    return _cabi.load()
+
+
+def make_conv_desc(**kw) -> ConvDesc:
+    d = ConvDesc()
+    defaults = dict(kh=1, kw=1, sh=1, sw=1, pt=0, pl=0, flip=0, dkh=1, dkw=1, wtap=0, nbias=0,
+                    accumulate=0, act_alpha=0.0)
+    defaults.update(kw)
+    for k, v in defaults.items():
+        setattr(d, k, v)
+    return d
+
+
+def _conv_sizes(d: ConvDesc):
+    x_elems = d.nimg * d.hin * d.win * d.cin
+    y_elems = d.nimg * d.hout * d.dkh * d.wout * d.dkw * d.cout
+    w_last = (d.kh * d.kw - 1) * d.wtap + (d.cin - 1) * d.wsk + (d.ngemm - 1) * d.wsn
+    return x_elems, y_elems, w_last + 1
+
+
+def conv_gemm(d: ConvDesc, x, w, bias, y, xmul=None, dact=None, accumulate=False, act_alpha=0.0):
+    xe, ye, we = _conv_sizes(d)
+    if x.numel() != xe or y.numel() != ye or w.numel() < we:
+        raise MgxError("conv_gemm: operand sizes do not match the descriptor (%d/%d, %d/%d, %d/%d)"
+                       % (x.numel(), xe, y.numel(), ye, w.numel(), we))
+    if xmul is not None and xmul.numel() != xe:
+        raise MgxError("conv_gemm: xmul size mismatch")
+    if dact is not None and dact.numel() != ye:
+        raise MgxError("conv_gemm: dact size mismatch")
+    if d.nbias and (bias is None or bias.numel() != d.nbias):
+        raise MgxError("conv_gemm: bias size mismatch")
+    d.accumulate = 1 if accumulate else 0
+    d.act_alpha = float(act_alpha)
+    check(_lib().mgx_conv_gemm_f32(C.byref(d), _p(x), _p(xmul), _p(w), _p(bias) if d.nbias else None,
+                                   _p(y), _p(dact), K.stream_ptr()), "mgx_conv_gemm_f32")
+
+
+def conv_wgrad(d: ConvDesc, x, dy, dw, dbias, dymul=None):
+    xe, ye, we = _conv_sizes(d)
+    if x.numel() != xe or dy.numel() != ye or dw.numel() < we:
+        raise MgxError("conv_wgrad: operand sizes do not match the descriptor")
+    if dymul is not None and dymul.numel() != ye:
+        raise MgxError("conv_wgrad: dymul size mismatch")
+    if dbias is not None and dbias.numel() != d.nbias:
+        raise MgxError("conv_wgrad: bias gradient size mismatch")
+    lib = _lib()
+    nbytes = lib.mgx_conv_wgrad_workspace(C.byref(d))
+    if nbytes <= 0:
+        raise MgxError("conv_wgrad: bad descriptor")
+    ws = K.workspace(nbytes)
+    check(lib.mgx_conv_wgrad_f32(C.byref(d), _p(x), _p(dy), _p(dymul), _p(dw), _p(dbias),
+                                 ws.data_ptr(), ws.numel(), K.stream_ptr()), "mgx_conv_wgrad_f32")
+
+
+def upsample2x_fwd(x, y, nimg, h, w, c):
+    if x.numel() != nimg * h * w * c or y.numel() != 4 * x.numel():
+        raise MgxError("upsample2x_fwd: size mismatch")
+    check(_lib().mgx_upsample2x_fwd(_p(x), _p(y), nimg, h, w, c, K.stream_ptr()), "mgx_upsample2x_fwd")
+
+
+def upsample2x_bwd(dy, dx, nimg, h, w, c, accumulate):
+    if dx.numel() != nimg * h * w * c or dy.numel() != 4 * dx.numel():
+        raise MgxError("upsample2x_bwd: size mismatch")
+    check(_lib().mgx_upsample2x_bwd(_p(dy), _p(dx), nimg, h, w, c, int(accumulate), K.stream_ptr()),
+          "mgx_upsample2x_bwd")
+
+
+def avgpool2x_fwd(x, y, nimg, h, w, c):
+    if x.numel() != nimg * h * w * c or 4 * y.numel() != x.numel():
+        raise MgxError("avgpool2x_fwd: size mismatch")
+    check(_lib().mgx_avgpool2x_fwd(_p(x), _p(y), nimg, h, w, c, K.stream_ptr()), "mgx_avgpool2x_fwd")
+
+
+def avgpool2x_bwd(dy, dx, nimg, h, w, c, accumulate):
+    if dx.numel() != nimg * h * w * c or 4 * dy.numel() != dx.numel():
+        raise MgxError("avgpool2x_bwd: size mismatch")
+    check(_lib().mgx_avgpool2x_bwd(_p(dy), _p(dx), nimg, h, w, c, int(accumulate), K.stream_ptr()),
+          "mgx_avgpool2x_bwd")
+
+
+def add_n(xs: Sequence[torch.Tensor], y):
+    n = y.numel()
+    if not 1 <= len(xs) <= 8 or any(t.numel() != n for t in xs):
+        raise MgxError("add_n: size mismatch")
+    arr = (C.c_void_p * len(xs))(*[_p(t) for t in xs])
+    check(_lib().mgx_add_n(arr, len(xs), _p(y), n, K.stream_ptr()), "mgx_add_n")
+
+
+def add_inplace(dst, src):
+    if dst.numel() != src.numel():
+        raise MgxError("add_inplace: size mismatch")
+    check(_lib().mgx_add_inplace(_p(dst), _p(src), dst.numel(), K.stream_ptr()), "mgx_add_inplace")
+
+
+def weighted_sum_fwd(a, b, alpha, y):
+    if a.numel() != b.numel() or a.numel() != y.numel() or alpha.numel() != 1:
+        raise MgxError("weighted_sum_fwd: size mismatch")
+    check(_lib().mgx_weighted_sum_fwd(_p(a), _p(b), _p(alpha), _p(y), y.numel(), K.stream_ptr()),
+          "mgx_weighted_sum_fwd")
+
+
+def weighted_sum_bwd(dy, a, b, alpha, da, acc_a, db, acc_b, dalpha):
+    n = dy.numel()
+    for t in (a, b, da, db):
+        if t is not None and t.numel() != n:
+            raise MgxError("weighted_sum_bwd: size mismatch")
+    lib = _lib()
+    ws = K.workspace(lib.mgx_reduce_workspace())
+    check(lib.mgx_weighted_sum_bwd(_p(dy), _p(a), _p(b), _p(alpha), _p(da), int(acc_a), _p(db), int(acc_b),
+                                   _p(dalpha), ws.data_ptr(), ws.numel(), n, K.stream_ptr()),
+          "mgx_weighted_sum_bwd")
+
+
+def layernorm_fwd(x, gamma, beta, y, stats, nimg, e, eps):
+    if x.numel() != nimg * e or y.numel() != nimg * e or gamma.numel() != e or beta.numel() != e \
+            or stats.numel() != 2 * nimg:
+        raise MgxError("layernorm_fwd: size mismatch")
+    lib = _lib()
+    ws = K.workspace(lib.mgx_layernorm_workspace(nimg, e))
+    check(lib.mgx_layernorm_fwd(_p(x), _p(gamma), _p(beta), _p(y), _p(stats), nimg, e, float(eps),
+                                ws.data_ptr(), ws.numel(), K.stream_ptr()), "mgx_layernorm_fwd")
+
+
+def layernorm_bwd(dy, x, gamma, stats, dx, acc_x, dgamma, dbeta, nimg, e):
+    if dy.numel() != nimg * e or x.numel() != nimg * e or gamma.numel() != e or stats.numel() != 2 * nimg:
+        raise MgxError("layernorm_bwd: size mismatch")
+    for t, n in ((dx, nimg * e), (dgamma, e), (dbeta, e)):
+        if t is not None and t.numel() != n:
+            raise MgxError("layernorm_bwd: size mismatch")
+    lib = _lib()
+    ws = K.workspace(lib.mgx_layernorm_workspace(nimg, e))
+    check(lib.mgx_layernorm_bwd(_p(dy), _p(x), _p(gamma), _p(stats), _p(dx), int(acc_x), _p(dgamma), _p(dbeta),
+                                nimg, e, ws.data_ptr(), ws.numel(), K.stream_ptr()), "mgx_layernorm_bwd")
+
+
+def mbstd_fwd(x, y, stat, n, h, w, c):
+    e = h * w * c
+    g = min(4, n)
+    if x.numel() != n * e or y.numel() != n * (e + w * c) or n % g or stat.numel() != n // g:
+        raise MgxError("mbstd_fwd: size mismatch (batch must be a multiple of min(4, batch))")
+    lib = _lib()
+    ws = K.workspace(lib.mgx_mbstd_workspace(n, e))
+    check(lib.mgx_mbstd_fwd(_p(x), _p(y), _p(stat), n, h, w, c, ws.data_ptr(), ws.numel(), K.stream_ptr()),
+          "mgx_mbstd_fwd")
+
+
+def mbstd_bwd(dy, x, dx, n, h, w, c):
+    e = h * w * c
+    if x.numel() != n * e or dx.numel() != n * e or dy.numel() != n * (e + w * c):
+        raise MgxError("mbstd_bwd: size mismatch")
+    lib = _lib()
+    ws = K.workspace(lib.mgx_mbstd_workspace(n, e))
+    check(lib.mgx_mbstd_bwd(_p(dy), _p(x), _p(dx), n, h, w, c, ws.data_ptr(), ws.numel(), K.stream_ptr()),
+          "mgx_mbstd_bwd")
+
+
+def softrect_fwd(x, y, alpha):
+    if x.numel() != y.numel():
+        raise MgxError("softrect_fwd: size mismatch")
+    check(_lib().mgx_softrect_fwd(_p(x), _p(y), x.numel(), float(alpha), K.stream_ptr()), "mgx_softrect_fwd")
+
+
+def softrect_bwd(dy, x, dx, accumulate, alpha):
+    if x.numel() != dy.numel() or x.numel() != dx.numel():
+        raise MgxError("softrect_bwd: size mismatch")
+    check(_lib().mgx_softrect_bwd(_p(dy), _p(x), _p(dx), int(accumulate), x.numel(), float(alpha), K.stream_ptr()),
+          "mgx_softrect_bwd")
+
+
+def dense1_fwd(x, w, b, y, n, e):
+    if x.numel() != n * e or w.numel() != e or y.numel() != n or (b is not None and b.numel() != 1):
+        raise MgxError("dense1_fwd: size mismatch")
+    check(_lib().mgx_dense1_fwd(_p(x), _p(w), _p(b), _p(y), n, e, K.stream_ptr()), "mgx_dense1_fwd")
+
+
+def dense1_bwd(dy, x, w, dx, dw, db, n, e):
+    if dy.numel() != n or x.numel() != n * e or w.numel() != e:
+        raise MgxError("dense1_bwd: size mismatch")
+    for t, m in ((dx, n * e), (dw, e), (db, 1)):
+        if t is not None and t.numel() != m:
+            raise MgxError("dense1_bwd: size mismatch")
+    check(_lib().mgx_dense1_bwd(_p(dy), _p(x), _p(w), _p(dx), _p(dw), _p(db), n, e, K.stream_ptr()),
+          "mgx_dense1_bwd")
+
+
+def logit_sums(fake, real, sums):
+    n = fake.numel() if fake is not None else real.numel()
+    if sums.numel() != 2 or (fake is not None and real is not None and fake.numel() != real.numel()):
+        raise MgxError("logit_sums: size mismatch")
+    check(_lib().mgx_logit_sums(_p(fake), _p(real), n, _p(sums), K.stream_ptr()), "mgx_logit_sums")
+
+
+def wgan_loss(sums, n_global, mode, out4, dfake, dreal, n_local):
+    if sums.numel() != 2 or (out4 is not None and out4.numel() != 4):
+        raise MgxError("wgan_loss: size mismatch")
+    for t in (dfake, dreal):
+        if t is not None and t.numel() != n_local:
+            raise MgxError("wgan_loss: size mismatch")
+    check(_lib().mgx_wgan_loss(_p(sums), n_global, mode, _p(out4), _p(dfake), _p(dreal), n_local, K.stream_ptr()),
+          "mgx_wgan_loss")
+
+
+def adam_multi(p_table, n_table, off_table, g_flat, v_flat, blk_tensor, blk_start, nblocks, lr_t, beta2, eps):
+    check(_lib().mgx_adam_multi(p_table.data_ptr(), n_table.data_ptr(), off_table.data_ptr(), _p(g_flat), _p(v_flat),
+                                blk_tensor.data_ptr(), blk_start.data_ptr(), nblocks, float(lr_t), float(beta2),
+                                float(eps), K.stream_ptr()), "mgx_adam_multi")

