@@ -5,8 +5,14 @@ Stated tolerances (float32 device arithmetic vs float64 oracle):
   metrics / losses      abs 2e-5 (values are O(1))
   logits                abs 2e-5
   generated audio       max abs 1e-4 (post-LayerNorm, O(1))
-  gradients             rel-L2 1e-4 per tensor on the stored checksum vector, or abs 1e-9 for
-                        tensors whose gradient is numerically zero
+  D-step gradients      rel-L2 5e-5 per tensor on the stored checksum vector (measured 2e-6..3e-5;
+                        the worst is the scalar Dense(1) bias, a cancelling sum of the two seeds)
+  G-step gradients      rel-L2 2e-3: they are taken AFTER the discriminator's Adam update, whose
+                        first step is sign-like (beta_1 = 0), so float32-level differences of
+                        near-zero D gradients move single D weights by up to ~1e-4; the saturated
+                        output tanh turns the resulting logit shift into a common factor
+                        exp(-2*dx) on every generator gradient (measured 2e-5..7e-4)
+                        (abs 1e-9 for tensors whose gradient is numerically zero)
   updated weights       abs 2e-5 on elements whose gradient is not within 1e-3 of the tensor's
                         rms (Adam with beta_1 = 0 is sign-like on its first step, so a 1-ulp sign
                         flip of a ~zero gradient moves the weight by 2*lr = 1e-3)
@@ -66,12 +72,15 @@ def device_step(name):
     d, g, comp, W = build(n_blocks, tr_alpha)
     gan = comp[stage][1 if fade else 0]
     real, z4 = R.synthetic_inputs(stage, batch, seed=0)
-    # the D step of the oracle records the generated audio: regenerate it here before the update
-    fake = gan.generator(z4[0]).cpu().numpy()
-    gan.inject_latents(z4)
     if ks:
         gan.set_train_steps(ks[1])
         gan.actual_step = ks[0]
+        for layer in gan.generator.layers:
+            if isinstance(layer, M.WeightedSum):
+                M.backend.set_value(layer.alpha, ks[0] / float(ks[1] - 1))
+    # the D step of the oracle records the generated audio: regenerate it here before the update
+    fake = gan.generator(z4[0]).cpu().numpy()
+    gan.inject_latents(z4)
     metrics = gan.train_step(real)
     torch.cuda.synchronize()
     return gan, metrics, fake
@@ -94,9 +103,10 @@ def test_train_step_matches_golden(name):
             if np.abs(want).max() < 1e-12:
                 assert np.abs(have).max() < 1e-9, v.name
             else:
+                tol = 5e-5 if prefix == "dgrad|" else 2e-3
                 err = rel_l2(have[2:], want[2:])
-                assert err < 1e-4, "%s%s: rel-L2 %.3e" % (prefix, v.name, err)
-                assert abs(have[1] - want[1]) <= 1e-4 * want[1] + 1e-12, v.name
+                assert err < tol, "%s%s: rel-L2 %.3e" % (prefix, v.name, err)
+                assert abs(have[1] - want[1]) <= tol * want[1] + 1e-12, v.name
     for model in (gan.discriminator, gan.generator):
         for v in model.trainable_variables:
             want = gold["w|" + v.name]
@@ -127,7 +137,8 @@ def test_train_step_matches_oracle_directly():
             if np.abs(want).max() < 1e-12:
                 assert np.abs(have).max() < 1e-9, v.name
             else:
-                assert rel_l2(have, want) < 1e-4, "%s: %.3e" % (v.name, rel_l2(have, want))
+                tol = 5e-5 if model is gan.discriminator else 2e-3
+                assert rel_l2(have, want) < tol, "%s: %.3e" % (v.name, rel_l2(have, want))
 
 
 @pytest.mark.parametrize("stage,fade", [(0, False), (2, False), (2, True)])
