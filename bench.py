@@ -1,0 +1,148 @@
+#!/usr/bin/env python3
+"""Benchmark of the G+D training step (trainer/models.py:72-158) on MI355X.
+
+    python bench.py --gpus N --steps K --warmup W            (N = 1: run directly;
+    N > 1: launched by torch.distributed.run, one rank per GPU, data parallel over RCCL)
+
+A "step" is one WGAN.train_step over one batch of synthetic audio that is already resident in
+HBM.  Default workload (N = 1): BASELINE.json configs[1] — mid-stage fade-in step, stage 3
+(32 x 6000), batch 64 per GPU, fp32.  With N GPUs the global batch is 64*N (weak scaling).
+
+Rank 0 prints ONE JSON line with, beside the contract fields,
+  roofline      the dominant kernel of the timed region: algorithmic FLOPs / launch duration,
+                measured with HIP events on the launch stream, against the dense f32 MFMA peak;
+  cpu_baseline  the CPU oracle's train step (float32, PyTorch-CPU) on a bounded sample of the
+                same workload, on this host's cores (N = 1 only).
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+if ROOT not in sys.path:
+    sys.path.insert(0, ROOT)
+
+F32_MFMA_PEAK_TFLOPS = 157.3      # dense f32 matrix peak of MI355X
+# train-step GFLOP per sample (6 G forwards-equivalents + 13 D), stages 0..6
+STEP_GFLOP_PER_SAMPLE = [13.6, 59.9, 245.0, 985.0, 3947.0, 15794.0, 63182.0]
+
+
+def cpu_baseline(stage, fade, sample_batch, n_blocks):
+    """Time the oracle's train step on the host (the reference's TensorFlow CPU path cannot run
+    here: TensorFlow/Keras are not installed)."""
+    import numpy as np
+    import torch
+    from oracle import ref_step as R
+    cores = min(16, os.cpu_count() or 1)
+    torch.set_num_threads(cores)
+    W = R.synthetic_weights(n_blocks, seed=100)
+    real, z4 = R.synthetic_inputs(stage, sample_batch, seed=0)
+    t0 = time.time()
+    R.train_step(W, n_blocks, stage, fade, real, z4, alpha=0.5 if fade else None, dtype=torch.float32,
+                 keep_grads=False)
+    dt = time.time() - t0
+    return {"value": sample_batch / dt, "unit": "samples/s", "cores": cores, "kind": "port",
+            "sample": "one oracle train step (float32, PyTorch-CPU) of the same stage-%d %s workload at batch %d, %.1f s"
+                      % (stage, "fade-in" if fade else "straight", sample_batch, dt)}
+
+
+def main():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--stage", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=64, help="per-GPU batch")
+    ap.add_argument("--straight", action="store_true", help="straight-through twin instead of fade-in")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-sample-batch", type=int, default=2)
+    args = ap.parse_args()
+
+    import numpy as np
+    import torch
+    import music_generator_amd as M
+    from music_generator_amd import ops
+    from music_generator_amd.parallel import DataParallel
+
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != args.gpus:
+        if world == 1 and args.gpus > 1:
+            raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node %d bench.py --gpus %d ..."
+                             % (args.gpus, args.gpus))
+    torch.cuda.set_device(local_rank)
+    dist = DataParallel(backend="nccl") if world > 1 else None
+
+    stage, fade = args.stage, (not args.straight and args.stage > 0)
+    n_blocks = stage + 1
+    M.clear_session()
+    d = M.define_discriminator(n_blocks)
+    g = M.define_generator(n_blocks)
+    comp = M.define_composite(d, g, (1, 100, 2))
+    gan = comp[stage][1 if fade else 0]
+    gan.dist = dist
+    if dist is not None:
+        dist.broadcast_weights(gan.discriminator, gan.generator)
+    gan.set_train_steps(100)
+    gan.seed(1234 + rank)
+    h, w = 4 << stage, 750 << stage
+    gen = torch.Generator(device="cuda")
+    gen.manual_seed(99 + rank)
+    real = torch.rand((args.batch, h, w, 2), device="cuda", generator=gen) * 2.0 - 1.0   # synthetic audio in HBM
+
+    def sync():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    for _ in range(args.warmup):
+        gan.train_step(real)
+    sync()
+    prof = ops.LaunchProfiler()
+    ops.PROFILER = prof
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        metrics = gan.train_step(real)
+    sync()
+    elapsed = time.perf_counter() - t0
+    ops.PROFILER = None
+    if dist is not None:
+        t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        elapsed = float(t.item())
+    last = {k: float(v) for k, v in metrics.items()}
+    if not all(np.isfinite(list(last.values()))):
+        raise SystemExit("non-finite metrics: %r" % (last,))
+
+    if rank != 0:
+        return
+    ms_per_step = elapsed / args.steps * 1e3
+    global_batch = args.batch * world
+    value = global_batch * args.steps / elapsed
+    summ = prof.summary()
+    key, (launches, ms, flops) = max(summ.items(), key=lambda kv: kv[1][1])
+    achieved = flops / (ms * 1e-3) / 1e12
+    contraction_ms = sum(v[1] for v in summ.values())
+    roofline = {"bound": "mfma", "kernel": key, "achieved": round(achieved, 2), "peak": F32_MFMA_PEAK_TFLOPS,
+                "unit": "TFLOP/s", "frac": round(achieved / F32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                "launches": launches, "avg_launch_ms": round(ms / launches, 4),
+                "share_of_step_time": round(ms / args.steps / ms_per_step, 3),
+                "all_contractions_share_of_step_time": round(contraction_ms / args.steps / ms_per_step, 3),
+                "step_tflops_algorithmic": round(STEP_GFLOP_PER_SAMPLE[stage] * args.batch / ms_per_step, 2)}
+    out = {"metric": "G+D train-step samples/sec", "value": round(value, 3), "unit": "samples/s", "n_gpus": world,
+           "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
+           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+           "config": {"workload": "stage-%d (%dx%d) %s G+D train step, batch %d per GPU, fp32"
+                                  % (stage, h, w, "fade-in" if fade else "straight-through", args.batch),
+                      "global_batch": global_batch, "parallelism": "dp%d" % world},
+           "roofline": roofline, "last_metrics": last}
+    if world == 1 and not args.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(stage, fade, args.cpu_sample_batch, n_blocks)
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()

@@ -25,6 +25,58 @@ def _lib():
     return _cabi.load()
 
 
+class LaunchProfiler:
+    """Optional per-launch timing of the contraction kernels with HIP events recorded on the
+    launch stream (set `ops.PROFILER = LaunchProfiler()`; None = off).  Keys mirror the template
+    instantiation the C side dispatches to, so they can be matched with a rocprofv3 kernel trace."""
+
+    def __init__(self):
+        self.records = []          # (key, flops, start_event, end_event)
+
+    def start(self):
+        e = torch.cuda.Event(enable_timing=True)
+        e.record()
+        return e
+
+    def stop(self, key, flops, e0):
+        e1 = torch.cuda.Event(enable_timing=True)
+        e1.record()
+        self.records.append((key, flops, e0, e1))
+
+    def summary(self):
+        """{key: (launches, total_ms, total_flops)} — call after torch.cuda.synchronize()."""
+        out = {}
+        for key, flops, e0, e1 in self.records:
+            n, ms, fl = out.get(key, (0, 0.0, 0.0))
+            out[key] = (n + 1, ms + e0.elapsed_time(e1), fl + flops)
+        return out
+
+
+PROFILER: Optional[LaunchProfiler] = None
+
+
+def _gemm_key(d: ConvDesc) -> str:
+    nt = (d.ngemm + 31) // 32
+    pn = "4,1" if nt == 1 else ("2,2" if nt == 2 else "2,4")
+    return "conv_gemm_kernel<%s,%d,%s>" % (pn, 0 if d.wsn == 1 else 1, "true" if d.cin % 8 == 0 else "false")
+
+
+def _wgrad_key(d: ConvDesc) -> str:
+    taps, kt, nt = d.kh * d.kw, (d.cin + 31) // 32, (d.ngemm + 31) // 32
+    if taps % 9 == 0:
+        return "wgrad_kernel<9,1,1>"
+    if taps % 8 == 0:
+        return "wgrad_kernel<8,1,1>"
+    if taps % 4 == 0:
+        return "wgrad_kernel<4,1,1>"
+    return "wgrad_kernel<1,%d,%d>" % (2 if kt >= 2 else 1, 4 if nt >= 4 else (2 if nt >= 2 else 1))
+
+
+def _conv_flops(d: ConvDesc) -> float:
+    """Algorithmic FLOPs of the contraction: 2 * rows * taps * cin * ngemm."""
+    return 2.0 * d.nimg * d.hout * d.wout * d.kh * d.kw * d.cin * d.ngemm
+
+
 def make_conv_desc(**kw) -> ConvDesc:
     d = ConvDesc()
     defaults = dict(kh=1, kw=1, sh=1, sw=1, pt=0, pl=0, flip=0, dkh=1, dkw=1, wtap=0, nbias=0,
@@ -55,8 +107,11 @@ def conv_gemm(d: ConvDesc, x, w, bias, y, xmul=None, dact=None, accumulate=False
         raise MgxError("conv_gemm: bias size mismatch")
     d.accumulate = 1 if accumulate else 0
     d.act_alpha = float(act_alpha)
+    e0 = PROFILER.start() if PROFILER is not None else None
     check(_lib().mgx_conv_gemm_f32(C.byref(d), _p(x), _p(xmul), _p(w), _p(bias) if d.nbias else None,
                                    _p(y), _p(dact), K.stream_ptr()), "mgx_conv_gemm_f32")
+    if e0 is not None:
+        PROFILER.stop(_gemm_key(d), _conv_flops(d), e0)
 
 
 def conv_wgrad(d: ConvDesc, x, dy, dw, dbias, dymul=None):
@@ -72,8 +127,11 @@ def conv_wgrad(d: ConvDesc, x, dy, dw, dbias, dymul=None):
     if nbytes <= 0:
         raise MgxError("conv_wgrad: bad descriptor")
     ws = K.workspace(nbytes)
+    e0 = PROFILER.start() if PROFILER is not None else None
     check(lib.mgx_conv_wgrad_f32(C.byref(d), _p(x), _p(dy), _p(dymul), _p(dw), _p(dbias),
                                  ws.data_ptr(), ws.numel(), K.stream_ptr()), "mgx_conv_wgrad_f32")
+    if e0 is not None:
+        PROFILER.stop(_wgrad_key(d), _conv_flops(d), e0)
 
 
 def upsample2x_fwd(x, y, nimg, h, w, c):
