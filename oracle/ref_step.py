@@ -547,7 +547,7 @@ def train_step(weights: Dict[str, np.ndarray], n_blocks: int, stage: int, fade_i
     real_logits = D(real_t)
     d_loss = discriminator_loss(fake_logits, real_logits)
     grads = torch.autograd.grad(d_loss, [W[n] for n in d_names])
-    res.d_loss = float(d_loss)
+    res.d_loss = float(d_loss.detach())
     res.fake_d_step = fake.detach().numpy().copy()
     res.fake_logits_d_step = fake_logits.detach().numpy().copy()
     res.real_logits_d_step = real_logits.detach().numpy().copy()
@@ -575,7 +575,7 @@ def train_step(weights: Dict[str, np.ndarray], n_blocks: int, stage: int, fade_i
         real_logits = D(real_t)
     g_loss = generator_loss(gen_logits, real_logits)
     grads = torch.autograd.grad(g_loss, [W[n] for n in g_names])
-    res.g_loss = float(g_loss)
+    res.g_loss = float(g_loss.detach())
     gg = {n: g.detach() for n, g in zip(g_names, grads)}
     if keep_grads:
         res.g_grads = {n: g.numpy().copy() for n, g in gg.items()}

@@ -1,0 +1,216 @@
+"""CPU tests of the host side: the models.py-compatible construction API (layer order, shared
+weights, shapes, names), the fade-in schedule arithmetic, the progressive driver's step counts,
+the data-parallel sharding rule (incl. a 2-rank gloo run), and that libmgx.so exports every
+symbol include/mgx.h declares.  No kernel is launched here.
+"""
+import ctypes
+import os
+import re
+import subprocess
+import sys
+
+import numpy as np
+import pytest
+import torch
+
+import music_generator_amd as M
+from music_generator_amd import _cabi, parallel, task
+from music_generator_amd.layers import Conv2D, Dense, LayerNormalization
+from oracle import ref_step as R
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_cabi_exports_every_declared_symbol():
+    header = open(os.path.join(ROOT, "include", "mgx.h")).read()
+    declared = set(re.findall(r"\b(mgx_[a-z0-9_]+)\s*\(", header))
+    assert declared == set(_cabi.PROTOTYPES), declared ^ set(_cabi.PROTOTYPES)
+    lib = ctypes.CDLL(_cabi.LIB_PATH)
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert _cabi.load().mgx_version() >= 1
+
+
+def test_missing_gpu_fails_loudly():
+    if torch.cuda.is_available():
+        pytest.skip("a GPU is visible")
+    d = M.define_discriminator(1)
+    with pytest.raises(RuntimeError):
+        d[0][0](np.zeros((4, 4, 750, 2), np.float32))
+
+
+def test_list_structure_and_shapes():
+    d = M.define_discriminator(3)
+    g = M.define_generator(3)
+    assert len(d) == 3 and len(g) == 3
+    assert d[0][0] is d[0][1] and g[0][0] is g[0][1]
+    assert d[1][0] is not d[1][1]
+    for s in range(3):
+        h, w = 4 << s, 750 << s
+        for tw in (0, 1):
+            assert g[s][tw].output_shape == (None, h, w, 2)
+            assert g[s][tw].input_shape == (None, 1, 100, 2)
+            assert d[s][tw].input_shape == (None, h, w, 2)
+            assert d[s][tw].output_shape == (None, 1)
+    assert list(d[1][0].input[0].shape) == [8, 1500, 2]
+
+
+def test_layers_are_shared_between_stages_and_twins():
+    d = M.define_discriminator(3)
+    g = M.define_generator(3)
+    # the stage-0 body is the tail of every later discriminator
+    tail0 = d[0][0].layers[3:-1]
+    for s in (1, 2):
+        for tw in (0, 1):
+            assert all(any(l is m for m in d[s][tw].layers) for l in tail0)
+    # fade-in twin re-uses the previous from-audio conv + activation (old_model.layers[1], [2])
+    assert any(l is d[0][0].layers[1] for l in d[1][1].layers)
+    assert not any(l is d[0][0].layers[1] for l in d[1][0].layers)
+    # generator: old LayerNormalization dropped, new one per twin, everything else shared
+    ln = [l for l in g[1][0].layers if isinstance(l, LayerNormalization)]
+    lnf = [l for l in g[1][1].layers if isinstance(l, LayerNormalization)]
+    assert len(ln) == 1 and len(lnf) == 1 and ln[0] is not lnf[0]
+    assert isinstance(g[1][0].layers[-1], LayerNormalization) and isinstance(g[1][0].layers[-2], Dense)
+    assert g[1][0].layers[-2].units == 2
+    assert isinstance(d[1][0].layers[1], Conv2D) and isinstance(d[1][0].layers[2], M.SoftRectifier)
+
+
+def test_variable_names_and_shapes_match_the_oracle_replay():
+    d = M.define_discriminator(3)
+    g = M.define_generator(3)
+    names, shapes = R.layer_names(3), R.weight_shapes(3)
+    for s in range(3):
+        for tw, fade in ((0, False), (1, True)):
+            for which, lst in (("d", d), ("g", g)):
+                model = lst[s][tw]
+                assert sorted(v.name for v in model.trainable_variables) == sorted(R.trainable_names(names, s, fade, which))
+                for v in model.trainable_variables:
+                    assert tuple(v.shape) == tuple(shapes[v.name])
+    assert d[0][0].count_params() == 252769 and g[0][0].count_params() == 226602
+
+
+def test_activation_constants_per_stage():
+    d = M.define_discriminator(7)
+    for s in range(7):
+        sot = [l for l in d[s][0].layers if isinstance(l, M.StaticOptTanh)]
+        assert len(sot) == 1 and sot[0].alpha == R.activation_alphas(s)[0]
+        first_sr = d[s][0].layers[2]
+        assert isinstance(first_sr, M.SoftRectifier) and first_sr.start_alpha == R.activation_alphas(s)[1]
+
+
+def test_fusion_plan_pairs_every_conv_with_its_activation():
+    d = M.define_discriminator(2)
+    plan = d[1][1]._plan
+    fused = [op for op in plan if op.act_node is not None]
+    # 11 new convs + old from-audio + 9 base convs + Dense(1) -> 22 fused launches
+    assert len(fused) == 22
+    assert all(isinstance(op.node.layer, (Conv2D, Dense)) for op in fused)
+
+
+def test_composite_and_optimizer_settings():
+    d = M.define_discriminator(2)
+    g = M.define_generator(2)
+    comp = M.define_composite(d, g, (1, 100, 2))
+    assert len(comp) == 2 and all(len(p) == 2 for p in comp)
+    gan = comp[1][1]
+    assert gan.fade_in and not comp[1][0].fade_in and gan.d_steps == 1
+    assert gan.discriminator is d[1][1] and gan.generator is g[1][1]
+    for opt in (gan.d_optimizer, gan.g_optimizer):
+        assert (opt.lr, opt.beta_1, opt.beta_2, opt.epsilon) == (0.0005, 0.0, 0.99, 10e-8)
+    assert comp[1][0].d_optimizer is not comp[1][1].d_optimizer
+    ws = [l for l in d[1][1].layers if isinstance(l, M.WeightedSum)]
+    assert len(ws) == 1 and ws[0].alpha.trainable
+    comp2 = M.define_composite(d, g, (1, 100, 2), trainable_alpha=False)
+    assert not ws[0].alpha.trainable and comp2[1][1].discriminator.count_params() == d[1][0].count_params() + 384
+
+
+def test_fade_in_needs_two_steps():
+    if not torch.cuda.is_available():
+        d = M.define_discriminator(2)
+        g = M.define_generator(2)
+        gan = M.define_composite(d, g, (1, 100, 2))[1][1]
+        gan.set_train_steps(1)
+        with pytest.raises(ValueError):
+            gan.train_step(np.zeros((4, 8, 1500, 2), np.float32))
+
+
+def test_schedule_constants_and_step_counts():
+    assert task.BATCH_SIZES == [16, 8, 4, 2, 2, 2, 2]
+    assert task.EPOCHS_NORM == [200, 220, 250, 280, 300, 350, 420]
+    assert task.EPOCHS_FADE == [10, 15, 32, 25, 30, 35, 40]
+    assert task.phase_steps(1003, 16, 200) == 62 * 200
+    assert task.phase_steps(37, 8, 15) == 4 * 15
+
+
+def test_shard_indices_keep_minibatch_groups_whole():
+    n, world = 32, 4
+    m = n // 4
+    seen = []
+    for r in range(world):
+        idx = parallel.shard_indices(n, r, world)
+        assert len(idx) == n // world
+        loc = idx.reshape(4, -1)                      # local [G, M/R]
+        for col in range(loc.shape[1]):
+            assert len({int(i) % m for i in loc[:, col]}) == 1      # one global group per local group
+            assert sorted(int(i) // m for i in loc[:, col]) == [0, 1, 2, 3]
+        seen.extend(idx.tolist())
+    assert sorted(seen) == list(range(n))
+    with pytest.raises(ValueError):
+        parallel.shard_indices(12, 0, 2)              # 3 groups do not split over 2 ranks
+
+
+_GLOO_WORKER = r"""
+import os, sys
+sys.path.insert(0, sys.argv[1])
+import numpy as np, torch, torch.distributed as dist
+from music_generator_amd.parallel import DataParallel, shard_indices
+from oracle import ref_step as R
+dp = DataParallel(backend="gloo")
+n_blocks, stage, batch = 1, 0, 8
+names = R.layer_names(n_blocks)
+W = {k: torch.tensor(v, dtype=torch.float64) for k, v in R.synthetic_weights(n_blocks, seed=100).items()}
+real, z4 = R.synthetic_inputs(stage, batch, seed=0)
+dn = R.trainable_names(names, stage, False, "d")
+
+def d_grads(real_b, z_b, n_global, sums=None):
+    P = {k: (v.clone().requires_grad_(True) if k in dn else v) for k, v in W.items()}
+    fake = R.generator(P, names, stage, False, torch.tensor(z_b, dtype=torch.float64))
+    fl = R.discriminator(P, names, stage, False, fake)
+    rl = R.discriminator(P, names, stage, False, torch.tensor(real_b, dtype=torch.float64))
+    local = torch.stack([fl.sum(), rl.sum()]).detach()
+    if sums is None:
+        return local
+    cu, ci = sums[0] / n_global, sums[1] / n_global
+    sgn = torch.sign(cu - ci)
+    # d(loss)/d(logit) with the GLOBAL batch in the denominator (parallel.py docstring)
+    loss = ((sgn + 1e-4) * rl.sum() - (sgn + 9.99e-5) * fl.sum()) / n_global
+    return torch.autograd.grad(loss, [P[k] for k in dn])
+
+idx = shard_indices(batch, dp.rank, dp.world_size)
+sums = d_grads(real[idx], z4[0][idx], batch)
+dp.all_reduce(sums)
+flat = torch.cat([g.reshape(-1) for g in d_grads(real[idx], z4[0][idx], batch, sums)])
+dp.all_reduce(flat)
+if dp.rank == 0:
+    full_sums = d_grads(real, z4[0], batch)
+    ref = torch.cat([g.reshape(-1) for g in d_grads(real, z4[0], batch, full_sums)])
+    err = float((flat - ref).norm() / ref.norm())
+    assert torch.allclose(sums, full_sums, rtol=1e-12, atol=1e-12), (sums, full_sums)
+    assert err < 1e-10, err
+    print("DP-OK", err)
+dist.destroy_process_group()
+"""
+
+
+def test_two_rank_gloo_data_parallel_equals_single_process(tmp_path):
+    """World-size-2 rehearsal on CPU (gloo): sharding by MinibatchStdDev groups + all-reduce of the
+    logit sums and of the gradients reproduces the single-process discriminator gradients.  The
+    per-rank arithmetic is the oracle's; what is under test is parallel.py's rule and collectives."""
+    script = tmp_path / "worker.py"
+    script.write_text(_GLOO_WORKER)
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29613", OMP_NUM_THREADS="2")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr",
+           "127.0.0.1", "--master-port", "29613", str(script), ROOT]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    assert "DP-OK" in out.stdout
