@@ -10,6 +10,10 @@
 #include "common.h"
 #include "../../include/mgx.h"
 
+bool mgx_tconv_applicable(const mgx_conv_desc& d);
+int mgx_tconv_launch(const mgx_conv_desc& d, const float* x, const float* xmul, const float* w, const float* bias,
+                     float* y, float* dact, hipStream_t st);
+
 namespace {
 
 struct RowPos {
@@ -215,6 +219,7 @@ extern "C" int mgx_conv_gemm_f32(const mgx_conv_desc* dp, const float* x, const 
     // the last gather position of every row grid must be reachable by construction of the layer:
     // out-of-range positions are treated as zero padding, never dereferenced.
     hipStream_t st = (hipStream_t)stream;
+    if (mgx_tconv_applicable(d)) return mgx_tconv_launch(d, x, xmul, w, bias, y, dact, st);
     const int ntiles = (d.ngemm + 31) / 32;
     if (ntiles == 1) return launch_pn<4, 1>(d, x, xmul, w, bias, y, dact, st);
     if (ntiles == 2) return launch_pn<2, 2>(d, x, xmul, w, bias, y, dact, st);

@@ -10,6 +10,11 @@
 #include "common.h"
 #include "../../include/mgx.h"
 
+bool mgx_twgrad_applicable(const mgx_conv_desc& d);
+long mgx_twgrad_splits(const mgx_conv_desc& d);
+int mgx_twgrad_launch(const mgx_conv_desc& d, const float* x, const float* dy, const float* dymul, float* partial,
+                      float* bpartial, hipStream_t st);
+
 namespace {
 
 struct WgradPlan {
@@ -20,6 +25,7 @@ struct WgradPlan {
     long rows_per_split;    // even
     long tiles_total;
     long partial_floats, bias_floats;
+    bool tiled;             // LDS-staged tile kernel (tconv.hip)
 };
 
 WgradPlan make_plan(const mgx_conv_desc& d) {
@@ -35,6 +41,17 @@ WgradPlan make_plan(const mgx_conv_desc& d) {
     else {
         p.KT = p.ktot >= 2 ? 2 : 1;
         p.NT = p.ntot >= 4 ? 4 : (p.ntot >= 2 ? 2 : 1);
+    }
+    p.tiled = mgx_twgrad_applicable(d);
+    if (p.tiled) {
+        p.T = p.ntaps; p.KT = 1; p.NT = 1;
+        p.tap_groups = 1; p.k_groups = p.ktot; p.n_groups = 1;
+        p.splits = mgx_twgrad_splits(d);
+        p.rows_per_split = 0;
+        p.tiles_total = (long)p.ntaps * p.ktot * p.ntot;
+        p.partial_floats = p.splits * p.tiles_total * 1024;
+        p.bias_floats = p.splits * p.ntot * 64;
+        return p;
     }
     p.tap_groups = p.ntaps / p.T;
     p.k_groups = (p.ktot + p.KT - 1) / p.KT;
@@ -173,42 +190,61 @@ __global__ __launch_bounds__(256) void wgrad_kernel(mgx_conv_desc d, const float
     }
 }
 
-// dW[tap*wtap + k*wsk + n*wsn] += sum_split partial[...]; one thread per (tap,k,n).
-__global__ __launch_bounds__(256) void wgrad_reduce_kernel(mgx_conv_desc d, const float* __restrict__ partial,
-                                                           float* __restrict__ dw, long splits, int ktot, int ntot,
-                                                           long tiles_total) {
-    const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+// dW[tap*wtap + k*wsk + n*wsn] += sum_split partial[...].  A block of 1024 threads covers 64
+// consecutive elements x 16 split groups (group g adds splits g, g+16, ... in order); the 16 group
+// sums are then added in a fixed tree, so the result does not depend on scheduling.
+__global__ __launch_bounds__(1024) void wgrad_reduce_kernel(mgx_conv_desc d, const float* __restrict__ partial,
+                                                            float* __restrict__ dw, long splits, int ktot, int ntot,
+                                                            long tiles_total) {
+    __shared__ float red[16][64];
+    const int e = threadIdx.x & 63, g = threadIdx.x >> 6;
+    const long idx = (long)blockIdx.x * 64 + e;
     const long per_tap = (long)d.cin * d.ngemm;
     const long total = (long)d.kh * d.kw * per_tap;
-    if (idx >= total) return;
-    const int tap = (int)(idx / per_tap);
-    const int rem = (int)(idx - tap * per_tap);
-    const int k = rem / d.ngemm, n = rem - k * d.ngemm;  // consecutive threads -> consecutive n
-    const long tile = ((long)tap * ktot + (k >> 5)) * ntot + (n >> 5);
-    const int i = k & 31, j = n & 31;
-    const int lane = j + 32 * ((i >> 2) & 1);
-    const int reg = (i & 3) + 4 * (i >> 3);
-    const float* src = partial + (tile * 16 + reg) * 64 + lane;
-    const long stride = tiles_total * 1024;
     float s = 0.f;
-    for (long sp = 0; sp < splits; ++sp) s += src[sp * stride];
-    dw[(long)tap * d.wtap + (long)k * d.wsk + (long)n * d.wsn] += s;
+    int tap = 0, k = 0, n = 0;
+    if (idx < total) {
+        tap = (int)(idx / per_tap);
+        const int rem = (int)(idx - tap * per_tap);
+        k = rem / d.ngemm;
+        n = rem - k * d.ngemm;  // consecutive threads -> consecutive n
+        const long tile = ((long)tap * ktot + (k >> 5)) * ntot + (n >> 5);
+        const int i = k & 31, j = n & 31;
+        const int lane = j + 32 * ((i >> 2) & 1);
+        const int reg = (i & 3) + 4 * (i >> 3);
+        const float* src = partial + (tile * 16 + reg) * 64 + lane;
+        const long stride = tiles_total * 1024;
+        for (long sp = g; sp < splits; sp += 16) s += src[sp * stride];
+    }
+    red[g][e] = s;
+    __syncthreads();
+    if (g == 0 && idx < total) {
+        float t[16];
+#pragma unroll
+        for (int q = 0; q < 16; ++q) t[q] = red[q][e];
+#pragma unroll
+        for (int w = 8; w > 0; w >>= 1)
+#pragma unroll
+            for (int q = 0; q < w; ++q) t[q] += t[q + w];
+        dw[(long)tap * d.wtap + (long)k * d.wsk + (long)n * d.wsn] += t[0];
+    }
 }
 
-// db[c] += sum over n == c (mod nbias), splits, lane halves.
-__global__ __launch_bounds__(64) void bias_reduce_kernel(mgx_conv_desc d, const float* __restrict__ bpartial,
-                                                         float* __restrict__ db, long splits, int ntot) {
-    const int c = blockIdx.x * 64 + threadIdx.x;
-    if (c >= d.nbias) return;
-    float s = 0.f;
+// db[c] += sum over n == c (mod nbias), splits, lane halves; one block per bias element.
+__global__ __launch_bounds__(256) void bias_reduce_kernel(mgx_conv_desc d, const float* __restrict__ bpartial,
+                                                          float* __restrict__ db, long splits, int ntot) {
+    __shared__ double red[4];
+    const int c = blockIdx.x;
+    double s = 0.0;
     for (int n = c; n < d.ngemm; n += d.nbias) {
         const int nt = n >> 5, j = n & 31;
-        for (long sp = 0; sp < splits; ++sp) {
+        for (long sp = threadIdx.x; sp < splits; sp += 256) {
             const float* src = bpartial + (sp * ntot + nt) * 64;
-            s += src[j] + src[j + 32];
+            s += (double)src[j] + (double)src[j + 32];
         }
     }
-    db[c] += s;
+    const double t = block_sum256_d(s, red);
+    if (threadIdx.x == 0) db[c] += (float)t;
 }
 
 template <int T, int KT, int NT>
@@ -240,7 +276,9 @@ extern "C" int mgx_conv_wgrad_f32(const mgx_conv_desc* dp, const float* x, const
     float* partial = (float*)workspace;
     float* bpartial = dbias ? partial + p.partial_floats : nullptr;
 #define MGX_WG(TT, KK, NN) launch_wgrad<TT, KK, NN>(d, p, x, dy, dymul, partial, bpartial, st)
-    if (p.T == 9) MGX_WG(9, 1, 1);
+    if (p.tiled) {
+        if (mgx_twgrad_launch(d, x, dy, dymul, partial, bpartial, st) != MGX_OK) return MGX_ERR_LAUNCH;
+    } else if (p.T == 9) MGX_WG(9, 1, 1);
     else if (p.T == 8) MGX_WG(8, 1, 1);
     else if (p.T == 4) MGX_WG(4, 1, 1);
     else if (p.KT == 1 && p.NT == 1) MGX_WG(1, 1, 1);
@@ -252,10 +290,10 @@ extern "C" int mgx_conv_wgrad_f32(const mgx_conv_desc* dp, const float* x, const
 #undef MGX_WG
     if (hipGetLastError() != hipSuccess) return MGX_ERR_LAUNCH;
     const long total = (long)d.kh * d.kw * d.cin * d.ngemm;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, d, partial, dw,
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((total + 63) / 64)), dim3(1024), 0, st, d, partial, dw,
                        p.splits, p.ktot, p.ntot, p.tiles_total);
     if (dbias)
-        hipLaunchKernelGGL(bias_reduce_kernel, dim3((unsigned)((d.nbias + 63) / 64)), dim3(64), 0, st, d, bpartial,
-                           dbias, p.splits, p.ntot);
+        hipLaunchKernelGGL(bias_reduce_kernel, dim3((unsigned)d.nbias), dim3(256), 0, st, d, bpartial, dbias, p.splits,
+                           p.ntot);
     return mgx_launch_status();
 }

@@ -51,6 +51,9 @@ CONV_CASES = [
     (4, 37, 128, 32, (3, 3), (1, 1), "same", 3),
     (4, 75, 32, 32, (4, 4), (1, 1), "same", 2),       # 4x4 'same' on H=4: pad 1 before / 2 after
     (8, 50, 32, 32, (3, 3), (1, 1), "same", 2),
+    (16, 70, 128, 32, (3, 3), (1, 1), "same", 2),     # LDS-tiled path, 4 input-channel chunks
+    (8, 33, 32, 32, (3, 3), (1, 1), "same", 3),       # LDS-tiled path, ragged right edge
+    (24, 95, 32, 32, (2, 2), (1, 1), "same", 1),
     (8, 50, 32, 32, (2, 2), (1, 1), "same", 2),       # 2x2 'same': pad 0 before / 1 after
     (8, 52, 32, 32, (2, 2), (2, 2), "valid", 3),
     (6, 41, 2, 128, (1, 1), (1, 1), "same", 2),
