@@ -76,6 +76,31 @@ int mgx_conv_wgrad_f32(const mgx_conv_desc* d, const float* x, const float* dy, 
                        float* dw, float* dbias, void* workspace, int64_t workspace_bytes, void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Fused forward of one generator grow block (add_generator_block, models.py:362-399): given the
+ * previous block's 2-channel output x (nimg, hl, wl, 2) it produces the new block's 2-channel output
+ * y (nimg, 2*hl, 2*wl, 2) = Dense(2)(Dense(8)(Dense(64)(Dense(256)(Add_k Dense(128)(ConvT(1,2)(Dense(32)(
+ * ConvT(2,1)(Conv2D(2,2,s2)(UpSampling2D(x)))))))))) without writing any intermediate tensor.
+ * Weights are the Keras-layout variables of the block's layers; `pack` is scratch of
+ * mgx_gblock_pack_floats() floats that the call refills from them.  Used for forwards that keep no
+ * tape (the generator passes of models.py:110, 125, 151 and inference, utils.py:81, 104).
+ * ------------------------------------------------------------------------------------------ */
+typedef struct {
+    const float *k0, *b0;            /* Conv2D(128,(2,2),s2): kernel (2,2,2,128), bias (128)      */
+    const float *k1[6], *b1[6];      /* Conv2DTranspose(16,(2,1)): kernel (2,1,16,128), bias (16)  */
+    const float *d1[6], *c1[6];      /* Dense(32): kernel (16,32), bias (32)                       */
+    const float *k2[6], *b2[6];      /* Conv2DTranspose(64,(1,2)): kernel (1,2,64,32), bias (64)   */
+    const float *d2[6], *c2[6];      /* Dense(128): kernel (64,128), bias (128)                    */
+    const float *w1, *e1;            /* Dense(256): (128,256), (256)                               */
+    const float *w2, *e2;            /* Dense(64):  (256,64),  (64)                                */
+    const float *w3, *e3;            /* Dense(8):   (64,8),    (8)                                 */
+    const float *w4, *e4;            /* Dense(2):   (8,2),     (2)                                 */
+} mgx_gblock_weights;
+
+int64_t mgx_gblock_pack_floats(void);
+int mgx_gblock_fwd_f32(const mgx_gblock_weights* w, float* pack, const float* x, float* y, int64_t nimg,
+                       int hl, int wl, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * Non-contraction layers (HBM-bound, coalesced, wavefront reductions)
  * ------------------------------------------------------------------------------------------ */
 

@@ -37,6 +37,15 @@ class ConvDesc(C.Structure):
     ]
 
 
+class GBlockWeights(C.Structure):
+    """mgx_gblock_weights of include/mgx.h (device pointers to one grow block's variables)."""
+    _fields_ = [("k0", C.c_void_p), ("b0", C.c_void_p),
+                ("k1", C.c_void_p * 6), ("b1", C.c_void_p * 6), ("d1", C.c_void_p * 6), ("c1", C.c_void_p * 6),
+                ("k2", C.c_void_p * 6), ("b2", C.c_void_p * 6), ("d2", C.c_void_p * 6), ("c2", C.c_void_p * 6),
+                ("w1", C.c_void_p), ("e1", C.c_void_p), ("w2", C.c_void_p), ("e2", C.c_void_p),
+                ("w3", C.c_void_p), ("e3", C.c_void_p), ("w4", C.c_void_p), ("e4", C.c_void_p)]
+
+
 _P = C.c_void_p
 _I64 = C.c_int64
 _I = C.c_int
@@ -49,6 +58,8 @@ PROTOTYPES = {
     "mgx_conv_gemm_f32": (_I, [_DESC, _P, _P, _P, _P, _P, _P, _P]),
     "mgx_conv_wgrad_workspace": (_I64, [_DESC]),
     "mgx_conv_wgrad_f32": (_I, [_DESC, _P, _P, _P, _P, _P, _P, _I64, _P]),
+    "mgx_gblock_pack_floats": (_I64, []),
+    "mgx_gblock_fwd_f32": (_I, [C.POINTER(GBlockWeights), _P, _P, _P, _I64, _I, _I, _P]),
     "mgx_upsample2x_fwd": (_I, [_P, _P, _I64, _I, _I, _I, _P]),
     "mgx_upsample2x_bwd": (_I, [_P, _P, _I64, _I, _I, _I, _I, _P]),
     "mgx_avgpool2x_fwd": (_I, [_P, _P, _I64, _I, _I, _I, _P]),

@@ -1,0 +1,242 @@
+// Fused forward of one generator grow block (add_generator_block, trainer/models.py:358-399):
+//   UpSampling2D -> Conv2D(128,(2,2),s2) -> 6 x {ConvT(16,(2,1)) -> Dense(32) -> ConvT(64,(1,2)) ->
+//   Dense(128)} -> Add -> Dense(256) -> Dense(64) -> Dense(8) -> Dense(2)
+// as ONE kernel on v_mfma_f32_32x32x2_f32.  A wave owns 32 low-resolution positions (= 128 output
+// positions); every layer is computed transposed, D[channel][position] = W^T * X, so that the
+// 32x32 accumulator tile of one layer (channel rows in the 16 registers x 2 lane halves, position
+// on the lane) is, register by register, the B operand of the next layer's MFMAs: activations
+// never leave the register file, no LDS, no intermediate tensor in HBM.  The contraction order
+// inside a 32-channel tile follows the accumulator layout (step s <-> channel (s&3)+8(s>>2)+4h);
+// a pack kernel rewrites the Keras-layout weights into that per-step, lane-ordered "fragment"
+// order once per call (615 KB, L2 resident).  Sub-row a of the 2x2 output block is the outer
+// loop (both sub-columns b share the branch prefix); the 128-wide featured tensor is recomputed
+// per branch (16 MFMAs) instead of being held in registers.
+#include "common.h"
+#include "../../include/mgx.h"
+
+namespace {
+
+// fragment offsets (units of 64 floats)
+constexpr int FR = 64;
+constexpr int OFF_F = 0;                 // featured conv: [ot 4][tap 4]
+constexpr int OFF_BR = 16;               // 6 branches x 264
+constexpr int BR_FR = 264;
+constexpr int BR_K1 = 0;                 // [it 4][s 16]         rows (a,co)
+constexpr int BR_D1 = 64;                // [s' 8]
+constexpr int BR_K2 = 72;                // [b 2][ot 2][s 16]
+constexpr int BR_D2 = 136;               // [ot 4][it 2][s 16]
+constexpr int OFF_W1 = OFF_BR + 6 * BR_FR;   // 1600: [c 8][it 4][s 16]
+constexpr int OFF_W2 = OFF_W1 + 512;         // 2112: [c 8][ot 2][s 16]
+constexpr int OFF_W3 = OFF_W2 + 256;         // 2368: [it 2][s 16]
+constexpr int OFF_W4 = OFF_W3 + 32;          // 2400: [s 4]
+constexpr int N_FR = OFF_W4 + 4;             // 2404
+constexpr int OFF_BSUM = N_FR * FR;          // 128 floats: sum of the six Dense(128) biases
+constexpr int OFF_BBR = OFF_BSUM + 128;      // per branch: b1 (16) | c1 (32) | b2 (64)
+constexpr int BBR = 112;
+constexpr int OFF_B0 = OFF_BBR + 6 * BBR;    // featured bias (128)
+constexpr int OFF_E1 = OFF_B0 + 128;         // tail biases 256 | 64 | 8 | 2
+constexpr int OFF_E2 = OFF_E1 + 256;
+constexpr int OFF_E3 = OFF_E2 + 64;
+constexpr int OFF_E4 = OFF_E3 + 8;
+constexpr int PACK_FLOATS = OFF_E4 + 8;
+
+__device__ __forceinline__ int chan(int s, int h) { return (s & 3) + 8 * (s >> 2) + 4 * h; }
+
+// ------------------------------------------------------------------------------------------
+// pack: one thread per packed float
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void gblock_pack_kernel(mgx_gblock_weights w, float* __restrict__ pack) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= PACK_FLOATS) return;
+    if (idx >= OFF_BSUM) {
+        float s = 0.f;
+        if (idx < OFF_BBR) {
+            for (int k = 0; k < 6; ++k) s += w.c2[k][idx - OFF_BSUM];
+        } else if (idx < OFF_B0) {
+            const int k = (idx - OFF_BBR) / BBR, e = (idx - OFF_BBR) % BBR;
+            s = e < 16 ? w.b1[k][e] : (e < 48 ? w.c1[k][e - 16] : w.b2[k][e - 48]);
+        } else if (idx < OFF_E1) s = w.b0[idx - OFF_B0];
+        else if (idx < OFF_E2) s = w.e1[idx - OFF_E1];
+        else if (idx < OFF_E3) s = w.e2[idx - OFF_E2];
+        else if (idx < OFF_E4) s = w.e3[idx - OFF_E3];
+        else s = (idx - OFF_E4) < 2 ? w.e4[idx - OFF_E4] : 0.f;
+        pack[idx] = s;
+        return;
+    }
+    const int fr = idx / FR, lane = idx % FR;
+    const int i = lane & 31, h = lane >> 5;
+    float v = 0.f;
+    if (fr < OFF_BR) {                                   // featured: K0[tap][c][n], (2,2,2,128)
+        const int ot = fr / 4, tap = fr % 4;
+        v = w.k0[(tap * 2 + h) * 128 + ot * 32 + i];
+    } else if (fr < OFF_W1) {
+        const int k = (fr - OFF_BR) / BR_FR, f = (fr - OFF_BR) % BR_FR;
+        if (f < BR_D1) {                                 // K1 (2,1,16,128): [a][co][ci]
+            const int it = f / 16, s = f % 16;
+            v = w.k1[k][((i >> 4) * 16 + (i & 15)) * 128 + it * 32 + chan(s, h)];
+        } else if (f < BR_K2) {                          // D1 (16,32): [in][out]
+            const int s = f - BR_D1;
+            v = w.d1[k][chan(s, h) * 32 + i];
+        } else if (f < BR_D2) {                          // K2 (1,2,64,32): [b][co][ci]
+            const int g = f - BR_K2;
+            const int b = g / 32, ot = (g % 32) / 16, s = g % 16;
+            v = w.k2[k][(b * 64 + ot * 32 + i) * 32 + chan(s, h)];
+        } else {                                         // D2 (64,128): [in][out]
+            const int g = f - BR_D2;
+            const int ot = g / 32, it = (g % 32) / 16, s = g % 16;
+            v = w.d2[k][(it * 32 + chan(s, h)) * 128 + ot * 32 + i];
+        }
+    } else if (fr < OFF_W2) {                            // W1 (128,256)
+        const int g = fr - OFF_W1;
+        const int c = g / 64, it = (g % 64) / 16, s = g % 16;
+        v = w.w1[(it * 32 + chan(s, h)) * 256 + c * 32 + i];
+    } else if (fr < OFF_W3) {                            // W2 (256,64)
+        const int g = fr - OFF_W2;
+        const int c = g / 32, ot = (g % 32) / 16, s = g % 16;
+        v = w.w2[(c * 32 + chan(s, h)) * 64 + ot * 32 + i];
+    } else if (fr < OFF_W4) {                            // W3 (64,8): rows >= 8 are zero
+        const int g = fr - OFF_W3;
+        const int it = g / 16, s = g % 16;
+        v = i < 8 ? w.w3[(it * 32 + chan(s, h)) * 8 + i] : 0.f;
+    } else {                                             // W4 (8,2): rows >= 2 are zero
+        const int s = fr - OFF_W4;
+        v = i < 2 ? w.w4[chan(s, h) * 2 + i] : 0.f;
+    }
+    pack[idx] = v;
+}
+
+// ------------------------------------------------------------------------------------------
+// forward
+// ------------------------------------------------------------------------------------------
+// acc += sum_{s in [S0, S0+NS)} frag[s-S0] (A operand: weights) x tile[s] (B operand: activations)
+template <int S0, int NS>
+__device__ __forceinline__ void mm(f32x16& acc, const f32x16& tile, const float* __restrict__ frag, int lane) {
+    float wv[NS];
+#pragma unroll
+    for (int s = 0; s < NS; ++s) wv[s] = frag[s * FR + lane];
+#pragma unroll
+    for (int s = 0; s < NS; ++s) acc = mfma32(wv[s], tile[S0 + s], acc);
+    // keep the fragment loads of later groups below this group's MFMAs: hoisting them all would
+    // need more registers than two waves per SIMD leave; the second wave covers the load latency
+    __builtin_amdgcn_sched_barrier(0);
+}
+
+// accumulator tile initialised with bias[c(reg,h) & mask] (rows >= valid are zero)
+__device__ __forceinline__ void init_bias(f32x16& acc, const float* __restrict__ bias, int h, int mask, int valid) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+        const int row0 = 8 * g + 4 * h;
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[4 * g + j] = (row0 + j) < valid ? bias[(row0 + j) & mask] : 0.f;
+    }
+}
+
+template <int A>
+__device__ __forceinline__ void half_block(const float* __restrict__ pack, float x0,
+                                           int lane, int h, bool pvalid, float* __restrict__ yrow0,
+                                           float* __restrict__ yrow1) {
+    f32x16 S[2][4];
+#pragma unroll
+    for (int b = 0; b < 2; ++b)
+#pragma unroll
+        for (int ot = 0; ot < 4; ++ot) init_bias(S[b][ot], pack + OFF_BSUM + ot * 32, h, 127, 32);
+    // the Add of the six branches: every branch contributes D2_k * o3_k; its bias is in bsum
+    for (int k = 0; k < 6; ++k) {
+        const float* bp = pack + (long)(OFF_BR + k * BR_FR) * FR;
+        const float* bb = pack + OFF_BBR + k * BBR;
+        // featured = sum over the 4 taps of the 2x2/s2 conv on the (nearest) up-sampled input: all four
+        // taps see the same low-resolution value, so each tap is one K=2 MFMA on (x[c=0], x[c=1])
+        f32x16 o1;
+        init_bias(o1, bb, h, 15, 32);
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            f32x16 F;
+            init_bias(F, pack + OFF_B0 + it * 32, h, 127, 32);
+#pragma unroll
+            for (int tap = 0; tap < 4; ++tap) F = mfma32(pack[(OFF_F + it * 4 + tap) * FR + lane], x0, F);
+            mm<0, 16>(o1, F, bp + (BR_K1 + it * 16) * FR, lane);
+        }
+        // Dense(32) on the 16 channels of sub-row A: registers 8A..8A+7 of o1
+        f32x16 o2;
+        init_bias(o2, bb + 16, h, 31, 32);
+        mm<8 * A, 8>(o2, o1, bp + BR_D1 * FR, lane);
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            f32x16 o3[2];
+#pragma unroll
+            for (int ot = 0; ot < 2; ++ot) {
+                init_bias(o3[ot], bb + 48 + ot * 32, h, 63, 32);
+                mm<0, 16>(o3[ot], o2, bp + (BR_K2 + (b * 2 + ot) * 16) * FR, lane);
+            }
+#pragma unroll
+            for (int ot = 0; ot < 4; ++ot)
+#pragma unroll
+                for (int it = 0; it < 2; ++it) mm<0, 16>(S[b][ot], o3[it], bp + (BR_D2 + (ot * 2 + it) * 16) * FR, lane);
+        }
+    }
+    // tail: Dense(256) in 8 chunks of 32 rows, each chunk immediately consumed by Dense(64)
+#pragma unroll
+    for (int b = 0; b < 2; ++b) {
+        f32x16 T2[2];
+        init_bias(T2[0], pack + OFF_E2, h, 63, 32);
+        init_bias(T2[1], pack + OFF_E2 + 32, h, 63, 32);
+        for (int c = 0; c < 8; ++c) {
+            f32x16 T1;
+            init_bias(T1, pack + OFF_E1 + c * 32, h, 255, 32);
+#pragma unroll
+            for (int it = 0; it < 4; ++it) mm<0, 16>(T1, S[b][it], pack + (long)(OFF_W1 + (c * 4 + it) * 16) * FR, lane);
+#pragma unroll
+            for (int ot = 0; ot < 2; ++ot) mm<0, 16>(T2[ot], T1, pack + (long)(OFF_W2 + (c * 2 + ot) * 16) * FR, lane);
+        }
+        f32x16 T3;
+        init_bias(T3, pack + OFF_E3, h, 7, 8);
+        mm<0, 16>(T3, T2[0], pack + (long)(OFF_W3)*FR, lane);
+        mm<0, 16>(T3, T2[1], pack + (long)(OFF_W3 + 16) * FR, lane);
+        f32x16 O;
+        init_bias(O, pack + OFF_E4, h, 1, 2);
+        mm<0, 4>(O, T3, pack + (long)OFF_W4 * FR, lane);
+        // rows 0,1 (the two output channels) live in registers 0,1 of lane half 0
+        if (pvalid && h == 0) {
+            float* dst = (A == 0 ? yrow0 : yrow1) + b * 2;
+            *(float2*)dst = make_float2(O[0], O[1]);
+        }
+    }
+}
+
+__global__ __launch_bounds__(256, 2) void gblock_fwd_kernel(const float* __restrict__ pack,
+                                                            const float* __restrict__ x, float* __restrict__ y,
+                                                            long npix, int hl, int wl) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const long p = ((long)blockIdx.x * 4 + wv) * 32 + r;
+    const bool pvalid = p < npix;
+    const long pc = pvalid ? p : 0;
+    // B operand of the featured conv: lane (position r, half h) supplies channel h of its position
+    const float x0 = x[pc * 2 + h];
+    const long row = pc / wl;                 // n*hl + i
+    const int j = (int)(pc - row * wl);
+    float* yrow0 = y + ((row * 2) * (2L * wl) + 2L * j) * 2;      // output row 2i,   column 2j
+    float* yrow1 = yrow0 + (2L * wl) * 2;                         // output row 2i+1
+    half_block<0>(pack, x0, lane, h, pvalid, yrow0, yrow1);
+    half_block<1>(pack, x0, lane, h, pvalid, yrow0, yrow1);
+}
+
+}  // namespace
+
+extern "C" int64_t mgx_gblock_pack_floats(void) { return PACK_FLOATS; }
+
+extern "C" int mgx_gblock_fwd_f32(const mgx_gblock_weights* wp, float* pack, const float* x, float* y, int64_t nimg,
+                                  int hl, int wl, void* stream) {
+    if (!wp || !pack || !x || !y || nimg <= 0 || hl <= 0 || wl <= 0) return MGX_ERR_ARG;
+    const mgx_gblock_weights w = *wp;
+    const void* const* ptrs = (const void* const*)&w;
+    for (size_t i = 0; i < sizeof(w) / sizeof(void*); ++i)
+        if (!ptrs[i]) return MGX_ERR_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(gblock_pack_kernel, dim3((PACK_FLOATS + 255) / 256), dim3(256), 0, st, w, pack);
+    const long npix = (long)nimg * hl * wl;
+    const long blocks = (npix + 127) / 128;
+    if (blocks > 0x7fffffffL) return MGX_ERR_ARG;
+    hipLaunchKernelGGL(gblock_fwd_kernel, dim3((unsigned)blocks), dim3(256), 0, st, pack, x, y, npix, hl, wl);
+    return mgx_launch_status();
+}

@@ -14,9 +14,20 @@
 #include "common.h"
 #include "../../include/mgx.h"
 
+#include <type_traits>
+
 namespace {
 
 constexpr int TH = 8, TW = 32, PSTR = 36;
+
+// compile-time unrolled loop: f(integral_constant<int, I>) for I in [0, N)
+template <int I, int N, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, N>(f);
+    }
+}
 
 template <int KH, int KW>
 constexpr int tconv_lds_bytes() { return (TH + KH - 1) * (TW + KW - 1) * PSTR * 4; }
@@ -38,7 +49,10 @@ __device__ __forceinline__ Tile decode_tile(long t, int tiles_h, int tiles_w) {
 }
 
 // Stage channels [c0, c0+32) of the (IH x IW) input window of a tile into LDS, stride `pstr`.
-template <int IH, int IW>
+// Every load is unconditional (out-of-image positions read a clamped, valid address and are then
+// replaced by zeros) so that the loads of one batch are issued back to back instead of being
+// branched around and waited for one by one.
+template <int IH, int IW, bool MUL>
 __device__ __forceinline__ void stage_tile(float* lds, int pstr, const float* __restrict__ x,
                                            const float* __restrict__ xmul, long img, int hbase, int wbase, int H,
                                            int W, int ctot, int c0) {
@@ -47,25 +61,33 @@ __device__ __forceinline__ void stage_tile(float* lds, int pstr, const float* __
     constexpr int BATCH = 4;   // float4 loads in flight per thread (bounds the staging registers)
     const int c4 = threadIdx.x & 7;
     const int p0 = threadIdx.x >> 3;
+    const long imgbase = img * H;
 #pragma unroll
     for (int i0 = 0; i0 < ITER; i0 += BATCH) {
-        f32x4 v[BATCH];
+        f32x4 v[BATCH], m[BATCH];
+        bool ok[BATCH];
 #pragma unroll
         for (int j = 0; j < BATCH; ++j) {
-            const int px = p0 + 32 * (i0 + j);
-            const int ty = px / IW, tx = px - ty * IW;
-            const int hi = hbase + ty, wi = wbase + tx;
-            v[j] = (f32x4){0.f, 0.f, 0.f, 0.f};
-            if (i0 + j < ITER && px < NPIX && hi >= 0 && hi < H && wi >= 0 && wi < W) {
-                const long off = ((img * H + hi) * W + wi) * (long)ctot + c0 + c4 * 4;
+            if (i0 + j < ITER) {
+                const int px = p0 + 32 * (i0 + j);
+                const int ty = px / IW, tx = px - ty * IW;
+                const int hi = hbase + ty, wi = wbase + tx;
+                ok[j] = px < NPIX && hi >= 0 && hi < H && wi >= 0 && wi < W;
+                const int hc = min(max(hi, 0), H - 1), wc = min(max(wi, 0), W - 1);
+                const long off = ((imgbase + hc) * W + wc) * (long)ctot + c0 + c4 * 4;
                 v[j] = *(const f32x4*)(x + off);
-                if (xmul) v[j] *= *(const f32x4*)(xmul + off);
+                if (MUL) m[j] = *(const f32x4*)(xmul + off);
             }
         }
 #pragma unroll
         for (int j = 0; j < BATCH; ++j) {
-            const int px = p0 + 32 * (i0 + j);
-            if (i0 + j < ITER && px < NPIX) *(f32x4*)(lds + px * pstr + c4 * 4) = v[j];
+            if (i0 + j < ITER) {
+                const int px = p0 + 32 * (i0 + j);
+                f32x4 val = v[j];
+                if (MUL) val *= m[j];
+                if (!ok[j]) val = (f32x4){0.f, 0.f, 0.f, 0.f};
+                if (px < NPIX) *(f32x4*)(lds + px * pstr + c4 * 4) = val;
+            }
         }
     }
 }
@@ -73,7 +95,7 @@ __device__ __forceinline__ void stage_tile(float* lds, int pstr, const float* __
 // ------------------------------------------------------------------------------------------
 // forward / data-gradient
 // ------------------------------------------------------------------------------------------
-template <int KH, int KW>
+template <int KH, int KW, bool WT>   // WT: weights stored [n][k] (wsk == 1, wsn == 32); else [k][n] (wsk == 32, wsn == 1)
 __global__ __launch_bounds__(256, 2) void tconv_kernel(mgx_conv_desc d, const float* __restrict__ x,
                                                        const float* __restrict__ xmul, const float* __restrict__ w,
                                                        const float* __restrict__ bias, float* __restrict__ y,
@@ -98,44 +120,40 @@ __global__ __launch_bounds__(256, 2) void tconv_kernel(mgx_conv_desc d, const fl
             for (int i = 0; i < 16; ++i) { acc[0][i] = 0.f; acc[1][i] = 0.f; }
             for (int kc = 0; kc < kchunks; ++kc) {
                 __syncthreads();  // every wave is done reading the previous contents
-                if (nc == 0 || kchunks > 1)
-                    stage_tile<IH, IW>(lds, PSTR, x, xmul, q.img, q.h0 - d.pt, q.w0 - d.pl, H, W, d.cin, kc * 32);
+                if (nc == 0 || kchunks > 1) {
+                    if (xmul) stage_tile<IH, IW, true>(lds, PSTR, x, xmul, q.img, q.h0 - d.pt, q.w0 - d.pl, H, W, d.cin, kc * 32);
+                    else stage_tile<IH, IW, false>(lds, PSTR, x, xmul, q.img, q.h0 - d.pt, q.w0 - d.pl, H, W, d.cin, kc * 32);
+                }
                 if (reload_w || !w_loaded) {
 #pragma unroll
                     for (int tap = 0; tap < TAPS; ++tap) {
                         const int wt = d.flip ? (TAPS - 1 - tap) : tap;
-                        const float* wp = w + (long)wt * d.wtap + (long)(kc * 32 + 16 * h) * d.wsk +
-                                          (long)(nc * 32 + r) * d.wsn;
+                        constexpr int WSK = WT ? 1 : 32, WSN = WT ? 32 : 1;   // compile-time strides: one
+                        const float* wp = w + (long)wt * d.wtap + (kc * 32 + 16 * h) * WSK +   // base address,
+                                          (nc * 32 + r) * WSN;                                  // immediate offsets
 #pragma unroll
-                        for (int s = 0; s < 16; ++s) wreg[tap][s] = wp[(long)s * d.wsk];
+                        for (int s = 0; s < 16; ++s) wreg[tap][s] = wp[s * WSK];
                     }
                     w_loaded = true;
                 }
                 __syncthreads();
-                // (tile row, tap) steps in a fixed order with a one-step register prefetch of the A
-                // fragment; the scheduling barrier keeps the compiler from hoisting every LDS read
-                // of the unrolled loop to the top (which would not fit the register file).
+                // (tile row, tap) steps in a fixed, fully unrolled order.  The scheduling barrier after
+                // each step keeps the compiler from hoisting the LDS reads of later steps to the top
+                // (the register file holds the weights); the second wave of the SIMD covers the wait.
                 const float* base = lds + ((wv * 2) * IW + r) * PSTR + 16 * h;
-                f32x4 cur[4], nxt[4];
+                static_for<0, 2 * TAPS>([&](auto step_c) {
+                    constexpr int step = decltype(step_c)::value;
+                    constexpr int pt = step / TAPS, tap = step % TAPS;
+                    const float* src = base + ((pt + tap / KW) * IW + (tap % KW)) * PSTR;
+                    f32x4 cur[4];
 #pragma unroll
-                for (int j = 0; j < 4; ++j) cur[j] = *(const f32x4*)(base + 4 * j);
-#pragma unroll
-                for (int step = 0; step < 2 * TAPS; ++step) {
-                    const int pt = step / TAPS, tap = step % TAPS;
-                    if (step + 1 < 2 * TAPS) {
-                        const int npt = (step + 1) / TAPS, ntap = (step + 1) % TAPS;
-                        const float* src = base + ((npt + ntap / KW) * IW + (ntap % KW)) * PSTR;
-#pragma unroll
-                        for (int j = 0; j < 4; ++j) nxt[j] = *(const f32x4*)(src + 4 * j);
-                    }
+                    for (int j = 0; j < 4; ++j) cur[j] = *(const f32x4*)(src + 4 * j);
 #pragma unroll
                     for (int j = 0; j < 4; ++j)
 #pragma unroll
                         for (int s = 0; s < 4; ++s) acc[pt] = mfma32(cur[j][s], wreg[tap][4 * j + s], acc[pt]);
                     __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) cur[j] = nxt[j];
-                }
+                });
             }
             // ---- epilogue for output channels [nc*32, nc*32+32) ----
             const int n = nc * 32 + r;
@@ -158,6 +176,8 @@ __global__ __launch_bounds__(256, 2) void tconv_kernel(mgx_conv_desc d, const fl
                     }
                     if (d.accumulate) v += y[off];
                     y[off] = v;
+                    // bound the live ranges of the unrolled epilogue (the weights stay in registers)
+                    if ((reg & 3) == 3) __builtin_amdgcn_sched_barrier(0);
                 }
             }
         }
@@ -196,8 +216,9 @@ __global__ __launch_bounds__(256, 2) void twgrad_kernel(mgx_conv_desc d, const f
     for (long t = blockIdx.x; t < ntiles; t += gridDim.x) {
         const Tile q = decode_tile(t, tiles_h, tiles_w);
         __syncthreads();
-        stage_tile<IH, IW>(xl, 32, x, nullptr, q.img, q.h0 - d.pt, q.w0 - d.pl, H, W, d.cin, kc * 32);
-        stage_tile<TH, TW>(gl, 32, dy, dymul, q.img, q.h0, q.w0, H, W, d.ngemm, 0);
+        stage_tile<IH, IW, false>(xl, 32, x, nullptr, q.img, q.h0 - d.pt, q.w0 - d.pl, H, W, d.cin, kc * 32);
+        if (dymul) stage_tile<TH, TW, true>(gl, 32, dy, dymul, q.img, q.h0, q.w0, H, W, d.ngemm, 0);
+        else stage_tile<TH, TW, false>(gl, 32, dy, dymul, q.img, q.h0, q.w0, H, W, d.ngemm, 0);
         __syncthreads();
 #pragma unroll 4
         for (int pp = 0; pp < 32; ++pp) {
@@ -245,6 +266,11 @@ bool mgx_tconv_applicable(const mgx_conv_desc& d) {
     if (d.cin > 128 || d.ngemm > 128) return false;
     if (d.hin % TH) return false;
     if (d.nbias != 0 && d.nbias != d.ngemm) return false;
+    // weight strides the kernels hard-code: [k][n] rows of 32 (forward) or [n][k] rows of 32 (data-gradient)
+    const bool kn = d.wsk == 32 && d.wsn == 1 && d.ngemm == 32;
+    const bool nk = d.wsk == 1 && d.wsn == 32 && d.cin == 32;
+    if (!kn && !nk) return false;
+    if (d.wtap != (int64_t)d.cin * d.ngemm) return false;
     return true;
 }
 
@@ -254,12 +280,12 @@ int mgx_tconv_launch(const mgx_conv_desc& d, const float* x, const float* xmul, 
     const long ntiles = (long)d.nimg * tiles_h * tiles_w;
     dim3 grid(tile_grid(ntiles)), block(256);
     constexpr int lds3 = tconv_lds_bytes<3, 3>(), lds2 = tconv_lds_bytes<2, 2>();
-    if (d.kh == 3)
-        hipLaunchKernelGGL((tconv_kernel<3, 3>), grid, block, lds3, st, d, x, xmul, w, bias, y, dact, ntiles, tiles_h,
-                           tiles_w);
-    else
-        hipLaunchKernelGGL((tconv_kernel<2, 2>), grid, block, lds2, st, d, x, xmul, w, bias, y, dact, ntiles, tiles_h,
-                           tiles_w);
+    const bool wt = d.wsk == 1;
+#define MGX_TC(KK, WW, LDS) \
+    hipLaunchKernelGGL((tconv_kernel<KK, KK, WW>), grid, block, LDS, st, d, x, xmul, w, bias, y, dact, ntiles, tiles_h, tiles_w)
+    if (d.kh == 3) { if (wt) MGX_TC(3, true, lds3); else MGX_TC(3, false, lds3); }
+    else { if (wt) MGX_TC(2, true, lds2); else MGX_TC(2, false, lds2); }
+#undef MGX_TC
     return mgx_launch_status();
 }
 

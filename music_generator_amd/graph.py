@@ -29,6 +29,7 @@ class KTensor:
     def __init__(self, shape: Tuple, node: Optional["Node"]):
         self.shape = tuple(shape)
         self.node = node
+        self.fused_group = None      # FusedGroup that can produce this tensor in one kernel
 
     def __getitem__(self, idx):
         # old_model.input[0].shape is used by add_discriminator_block (models.py:231)
@@ -139,8 +140,26 @@ class _Op:
         self.output = act_node.output if act_node is not None else node.output
 
 
+class FusedGroup:
+    """A sub-graph (input tensor -> output tensor through `nodes`) for which one fused kernel
+    exists.  Used only by forwards that keep no tape; `run(x)` returns the output tensor."""
+
+    def __init__(self, input: KTensor, output: KTensor, nodes: List[Node], optional_nodes: List[Node], run):
+        self.input, self.output, self.nodes, self.optional_nodes, self.run = input, output, nodes, optional_nodes, run
+
+
+class _FusedOp:
+    def __init__(self, group: FusedGroup):
+        self.group = group
+        self.inputs = [group.input]
+        self.output = group.output
+        self.act_node = None
+
+
 class Model:
     """keras.Model(inputs, outputs) for single-input single-output graphs."""
+
+    use_fused_groups = True      # tape-free forwards may use fused sub-graph kernels
 
     def __init__(self, inputs: KTensor, outputs: KTensor, name: Optional[str] = None):
         if isinstance(inputs, (list, tuple)) or isinstance(outputs, (list, tuple)):
@@ -215,11 +234,49 @@ class Model:
                     fused.add(id(act))
             plan.append(_Op(node, act))
         self._plan = plan
+        self._last_use = self._compute_last_use(plan)
+
+        # tape-free plan: replace every fusable sub-graph that lies wholly inside this model
+        in_model = {id(n) for n in order}
+        groups = [n.output.fused_group for n in order if n.output.fused_group is not None]
+        drop, emit_at = set(), {}
+        for g in groups:
+            if not all(id(n) in in_model for n in g.nodes):
+                continue
+            inner = {id(n) for n in g.nodes}
+            # an optional node (e.g. the UpSampling2D whose output also feeds the fade-in blend) is
+            # dropped only when nothing outside the group consumes it in this model
+            for n in g.optional_nodes:
+                if id(n) in in_model and all(id(c) in inner for c in consumers.get(id(n.output), [])):
+                    inner.add(id(n))
+            escapes = any(id(c) not in inner for n in g.nodes if n.output is not g.output
+                          for c in consumers.get(id(n.output), []))
+            if escapes or any(n.output is self.output and n.output is not g.output for n in g.nodes):
+                continue
+            drop |= inner
+            emit_at[id(g.output.node)] = g
+        if emit_at:
+            plan_i: List = []
+            for op in plan:
+                nid = id(op.node)
+                if nid in emit_at:
+                    plan_i.append(_FusedOp(emit_at[nid]))
+                elif nid in drop or (op.act_node is not None and id(op.act_node) in drop):
+                    continue
+                else:
+                    plan_i.append(op)
+            self._plan_infer = plan_i
+        else:
+            self._plan_infer = plan
+        self._last_use_infer = self._compute_last_use(self._plan_infer)
+
+    @staticmethod
+    def _compute_last_use(plan):
         last_use: Dict[int, int] = {}
         for i, op in enumerate(plan):
             for it in op.inputs:
                 last_use[id(it)] = i
-        self._last_use = last_use
+        return last_use
 
     @property
     def output_shape(self):
@@ -269,8 +326,16 @@ class Model:
         x = self._to_device(x)
         vals: Dict[int, torch.Tensor] = {id(self.input): x}
         tape = [] if save else None
-        for i, op in enumerate(self._plan):
+        plan = self._plan if (save or not Model.use_fused_groups) else self._plan_infer
+        last_use = self._last_use if plan is self._plan else self._last_use_infer
+        for i, op in enumerate(plan):
             xs = [vals[id(t)] for t in op.inputs]
+            if isinstance(op, _FusedOp):
+                vals[id(op.output)] = op.group.run(xs[0])
+                for t in op.inputs:
+                    if last_use.get(id(t)) == i and t is not self.output:
+                        vals.pop(id(t), None)
+                continue
             if op.act_node is not None:
                 y, saved = op.node.layer.forward(xs, save, act_alpha=op.act_node.layer.alpha_value)
             else:
@@ -279,7 +344,7 @@ class Model:
             if save:
                 tape.append(saved)
             for t in op.inputs:
-                if self._last_use.get(id(t)) == i and t is not self.output:
+                if last_use.get(id(t)) == i and t is not self.output:
                     vals.pop(id(t), None)
         return vals[id(self.output)], tape
 

@@ -19,7 +19,8 @@ import torch
 from . import backend
 from . import backend as K
 from . import ops
-from .graph import Input, Layer, Model
+from . import _cabi
+from .graph import FusedGroup, Input, Layer, Model
 from .layers import (Add, AveragePooling2D, Conv2D, Conv2DTranspose, Dense, Flatten, LayerNormalization,
                      UpSampling2D)
 
@@ -220,6 +221,50 @@ def _g_tail(t):
     return t
 
 
+def _register_fused_block(block_end, upsampling, for_sum_layer):
+    """Describe the sub-graph block_end -> for_sum_layer of add_generator_block to the executor so
+    that forwards without a tape run it as the single fused kernel mgx_gblock_fwd_f32."""
+    nodes, t = [], for_sum_layer
+    tail = []
+    for _ in range(4):                       # Dense(2) <- Dense(8) <- Dense(64) <- Dense(256)
+        tail.append(t.node)
+        t = t.node.inputs[0]
+    add_node = t.node
+    branch_nodes = []
+    for bt in add_node.inputs:               # Dense(128) <- ConvT(1,2) <- Dense(32) <- ConvT(2,1)
+        chain, u = [], bt
+        for _ in range(4):
+            chain.append(u.node)
+            u = u.node.inputs[0]
+        branch_nodes.append(chain[::-1])
+    feat_node = branch_nodes[0][0].inputs[0].node
+    nodes = [feat_node] + [n for ch in branch_nodes for n in ch] + [add_node] + tail
+    tail_layers = [n.layer for n in tail[::-1]]   # Dense(256), Dense(64), Dense(8), Dense(2)
+    state = {}
+
+    def run(x):
+        if "w" not in state:
+            w = _cabi.GBlockWeights()
+            f = feat_node.layer
+            w.k0, w.b0 = f.kernel.value().data_ptr(), f.bias.value().data_ptr()
+            for k, ch in enumerate(branch_nodes):
+                for name_k, name_b, node in (("k1", "b1", ch[0]), ("d1", "c1", ch[1]), ("k2", "b2", ch[2]),
+                                             ("d2", "c2", ch[3])):
+                    getattr(w, name_k)[k] = node.layer.kernel.value().data_ptr()
+                    getattr(w, name_b)[k] = node.layer.bias.value().data_ptr()
+            for i, layer in enumerate(tail_layers):
+                setattr(w, "w%d" % (i + 1), layer.kernel.value().data_ptr())
+                setattr(w, "e%d" % (i + 1), layer.bias.value().data_ptr())
+            state["w"] = w
+            state["pack"] = K.empty((ops.gblock_pack_floats(),))
+        n, hl, wl, _ = x.shape
+        y = K.empty((n, 2 * hl, 2 * wl, 2))
+        ops.gblock_fwd(state["w"], state["pack"], x, y, n, hl, wl)
+        return y
+
+    for_sum_layer.fused_group = FusedGroup(block_end, for_sum_layer, nodes, [upsampling.node], run)
+
+
 def add_generator_block(old_model):
     block_end = old_model.layers[-2].output          # last Dense(2), before its LayerNormalization
     upsampling = UpSampling2D()(block_end)
@@ -231,6 +276,7 @@ def add_generator_block(old_model):
         g = Conv2DTranspose(64, (1, 2), strides=(1, 2), padding="valid", kernel_initializer="he_normal")(g)
         branches.append(Dense(128)(g))
     for_sum_layer = _g_tail(Add()(branches))
+    _register_fused_block(block_end, upsampling, for_sum_layer)
     model1 = Model(old_model.input, LayerNormalization(axis=[1, 2, 3])(for_sum_layer))
     merged = WeightedSum()([upsampling, for_sum_layer])
     model2 = Model(old_model.input, LayerNormalization(axis=[1, 2, 3])(merged))

@@ -134,6 +134,18 @@ def conv_wgrad(d: ConvDesc, x, dy, dw, dbias, dymul=None):
         PROFILER.stop(_wgrad_key(d), _conv_flops(d), e0)
 
 
+def gblock_pack_floats() -> int:
+    return int(_lib().mgx_gblock_pack_floats())
+
+
+def gblock_fwd(weights, pack, x, y, nimg, hl, wl):
+    """weights: _cabi.GBlockWeights; x (nimg,hl,wl,2) -> y (nimg,2hl,2wl,2)."""
+    if x.numel() != nimg * hl * wl * 2 or y.numel() != 4 * x.numel() or pack.numel() < gblock_pack_floats():
+        raise MgxError("gblock_fwd: size mismatch")
+    check(_lib().mgx_gblock_fwd_f32(C.byref(weights), _p(pack), _p(x), _p(y), nimg, hl, wl, K.stream_ptr()),
+          "mgx_gblock_fwd_f32")
+
+
 def upsample2x_fwd(x, y, nimg, h, w, c):
     if x.numel() != nimg * h * w * c or y.numel() != 4 * x.numel():
         raise MgxError("upsample2x_fwd: size mismatch")
