@@ -14,6 +14,8 @@
 #include "common.h"
 #include "../../include/mgx.h"
 
+#include <type_traits>
+
 namespace {
 
 // fragment offsets (units of 64 floats)
@@ -108,102 +110,135 @@ __global__ __launch_bounds__(256) void gblock_pack_kernel(mgx_gblock_weights w, 
 // ------------------------------------------------------------------------------------------
 // forward
 // ------------------------------------------------------------------------------------------
-// acc += sum_{s in [S0, S0+NS)} frag[s-S0] (A operand: weights) x tile[s] (B operand: activations)
-template <int S0, int NS>
-__device__ __forceinline__ void mm(f32x16& acc, const f32x16& tile, const float* __restrict__ frag, int lane) {
-    float wv[NS];
+// Weight fragments stream through two register buffers of 16: while the MFMAs of one group run
+// from buffer P, the fragments of the next group are loaded into buffer P^1 (their L2 latency is
+// covered by the 16 x 64 cycles of the running group).  Buffer parities are compile-time: every
+// rolled loop body holds an even number of groups.
+struct WBuf {
+    float v[2][16];
+};
+
+template <int P, int NS>
+__device__ __forceinline__ void pf(WBuf& B, const float* __restrict__ frag, int lane) {
 #pragma unroll
-    for (int s = 0; s < NS; ++s) wv[s] = frag[s * FR + lane];
-#pragma unroll
-    for (int s = 0; s < NS; ++s) acc = mfma32(wv[s], tile[S0 + s], acc);
-    // keep the fragment loads of later groups below this group's MFMAs: hoisting them all would
-    // need more registers than two waves per SIMD leave; the second wave covers the load latency
-    __builtin_amdgcn_sched_barrier(0);
+    for (int s = 0; s < NS; ++s) B.v[P][s] = frag[s * FR + lane];
 }
 
-// accumulator tile initialised with bias[c(reg,h) & mask] (rows >= valid are zero)
-__device__ __forceinline__ void init_bias(f32x16& acc, const float* __restrict__ bias, int h, int mask, int valid) {
+// acc += sum_{s < NS} B.v[P][s] (A operand: weights) x tile[S0 + s] (B operand: activations)
+template <int P, int S0, int NS>
+__device__ __forceinline__ void mma(f32x16& acc, const f32x16& tile, const WBuf& B) {
+#pragma unroll
+    for (int s = 0; s < NS; ++s) acc = mfma32(B.v[P][s], tile[S0 + s], acc);
+}
+
+#define MGX_FENCE() __builtin_amdgcn_sched_barrier(0)
+
+__device__ __forceinline__ const float* fptr(const float* pack, int frag) { return pack + (long)frag * FR; }
+
+// accumulator tile initialised with bias rows c(reg,h): registers 4g..4g+3 are the 4 consecutive
+// rows 8g+4h.. (one 16-byte load each); groups g >= ngroups start at zero
+__device__ __forceinline__ void init_bias(f32x16& acc, const float* __restrict__ bias, int h, int mask, int ngroups) {
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
-        const int row0 = 8 * g + 4 * h;
+        f32x4 v = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (g < ngroups) v = *(const f32x4*)(bias + ((8 * g + 4 * h) & mask));
 #pragma unroll
-        for (int j = 0; j < 4; ++j) acc[4 * g + j] = (row0 + j) < valid ? bias[(row0 + j) & mask] : 0.f;
+        for (int j = 0; j < 4; ++j) acc[4 * g + j] = v[j];
     }
 }
 
-template <int A>
-__device__ __forceinline__ void half_block(const float* __restrict__ pack, float x0,
-                                           int lane, int h, bool pvalid, float* __restrict__ yrow0,
-                                           float* __restrict__ yrow1) {
+// One sub-row A of the 2x2 output block, both sub-columns.  On entry buffer PS holds the 16
+// featured-conv fragments; on exit buffer PS^1 holds the 16 fragments at `after` (if LAST is false).
+template <int A, int PS, bool LAST>
+__device__ __forceinline__ void half_block(const float* __restrict__ pack, float x0, int lane, int h, bool pvalid,
+                                           float* __restrict__ yrow, WBuf& B, const float* __restrict__ after) {
+    constexpr int P0 = PS, P1 = PS ^ 1;
     f32x16 S[2][4];
 #pragma unroll
     for (int b = 0; b < 2; ++b)
 #pragma unroll
-        for (int ot = 0; ot < 4; ++ot) init_bias(S[b][ot], pack + OFF_BSUM + ot * 32, h, 127, 32);
-    // the Add of the six branches: every branch contributes D2_k * o3_k; its bias is in bsum
+        for (int ot = 0; ot < 4; ++ot) init_bias(S[b][ot], pack + OFF_BSUM + ot * 32, h, 127, 4);
+    // featured = sum over the 4 taps of the 2x2/s2 conv on the (nearest) up-sampled input: the four taps
+    // see the same low-resolution value, so each tap is one K=2 MFMA on (x[c=0], x[c=1])
+    f32x16 F[4];
+#pragma unroll
+    for (int it = 0; it < 4; ++it) init_bias(F[it], pack + OFF_B0 + it * 32, h, 127, 4);
+    pf<P1, 16>(B, fptr(pack, OFF_BR + BR_K1), lane);
+#pragma unroll
+    for (int it = 0; it < 4; ++it)
+#pragma unroll
+        for (int tap = 0; tap < 4; ++tap) F[it] = mfma32(B.v[P0][it * 4 + tap], x0, F[it]);
+    MGX_FENCE();
+
+    // six branches (26 groups each); every branch adds D2_k * o3_k into S, its bias is in bsum
     for (int k = 0; k < 6; ++k) {
-        const float* bp = pack + (long)(OFF_BR + k * BR_FR) * FR;
+        const int bf = OFF_BR + k * BR_FR;
         const float* bb = pack + OFF_BBR + k * BBR;
-        // featured = sum over the 4 taps of the 2x2/s2 conv on the (nearest) up-sampled input: all four
-        // taps see the same low-resolution value, so each tap is one K=2 MFMA on (x[c=0], x[c=1])
-        f32x16 o1;
-        init_bias(o1, bb, h, 15, 32);
-#pragma unroll
-        for (int it = 0; it < 4; ++it) {
-            f32x16 F;
-            init_bias(F, pack + OFF_B0 + it * 32, h, 127, 32);
-#pragma unroll
-            for (int tap = 0; tap < 4; ++tap) F = mfma32(pack[(OFF_F + it * 4 + tap) * FR + lane], x0, F);
-            mm<0, 16>(o1, F, bp + (BR_K1 + it * 16) * FR, lane);
-        }
+        f32x16 o1, o2;
+        init_bias(o1, bb, h, 15, 4);
+        pf<P0, 16>(B, fptr(pack, bf + BR_K1 + 16), lane); mma<P1, 0, 16>(o1, F[0], B); MGX_FENCE();
+        pf<P1, 16>(B, fptr(pack, bf + BR_K1 + 32), lane); mma<P0, 0, 16>(o1, F[1], B); MGX_FENCE();
+        pf<P0, 16>(B, fptr(pack, bf + BR_K1 + 48), lane); mma<P1, 0, 16>(o1, F[2], B); MGX_FENCE();
+        pf<P1, 4>(B, fptr(pack, bf + BR_D1), lane);       mma<P0, 0, 16>(o1, F[3], B); MGX_FENCE();
         // Dense(32) on the 16 channels of sub-row A: registers 8A..8A+7 of o1
-        f32x16 o2;
-        init_bias(o2, bb + 16, h, 31, 32);
-        mm<8 * A, 8>(o2, o1, bp + BR_D1 * FR, lane);
+        init_bias(o2, bb + 16, h, 31, 4);
+        pf<P0, 4>(B, fptr(pack, bf + BR_D1 + 4), lane);   mma<P1, 8 * A, 4>(o2, o1, B); MGX_FENCE();
+        pf<P1, 16>(B, fptr(pack, bf + BR_K2), lane);      mma<P0, 8 * A + 4, 4>(o2, o1, B); MGX_FENCE();
 #pragma unroll
         for (int b = 0; b < 2; ++b) {
             f32x16 o3[2];
+            init_bias(o3[0], bb + 48, h, 63, 4);
+            init_bias(o3[1], bb + 80, h, 63, 4);
+            pf<P0, 16>(B, fptr(pack, bf + BR_K2 + (b * 2 + 1) * 16), lane); mma<P1, 0, 16>(o3[0], o2, B); MGX_FENCE();
+            pf<P1, 16>(B, fptr(pack, bf + BR_D2), lane);                    mma<P0, 0, 16>(o3[1], o2, B); MGX_FENCE();
 #pragma unroll
-            for (int ot = 0; ot < 2; ++ot) {
-                init_bias(o3[ot], bb + 48 + ot * 32, h, 63, 32);
-                mm<0, 16>(o3[ot], o2, bp + (BR_K2 + (b * 2 + ot) * 16) * FR, lane);
+            for (int g = 0; g < 8; g += 2) {       // D2 groups g = ot*2 + it
+                pf<P0, 16>(B, fptr(pack, bf + BR_D2 + (g + 1) * 16), lane);
+                mma<P1, 0, 16>(S[b][g / 2], o3[0], B); MGX_FENCE();
+                const float* nxt;
+                if (g < 6) nxt = fptr(pack, bf + BR_D2 + (g + 2) * 16);
+                else if (b == 0) nxt = fptr(pack, bf + BR_K2 + 32);
+                else nxt = k < 5 ? fptr(pack, bf + BR_FR + BR_K1) : fptr(pack, OFF_W1);
+                pf<P1, 16>(B, nxt, lane);
+                mma<P0, 0, 16>(S[b][g / 2], o3[1], B); MGX_FENCE();
             }
-#pragma unroll
-            for (int ot = 0; ot < 4; ++ot)
-#pragma unroll
-                for (int it = 0; it < 2; ++it) mm<0, 16>(S[b][ot], o3[it], bp + (BR_D2 + (ot * 2 + it) * 16) * FR, lane);
         }
     }
-    // tail: Dense(256) in 8 chunks of 32 rows, each chunk immediately consumed by Dense(64)
-#pragma unroll
-    for (int b = 0; b < 2; ++b) {
+    // tail (51 groups per sub-column): Dense(256) in 8 chunks of 32 rows, each chunk immediately consumed by
+    // Dense(64); then Dense(8), Dense(2).  Entry: buffer Q holds W1 chunk 0 / input tile 0.
+    auto tail = [&](auto qc, auto bc) {
+        constexpr int Q = decltype(qc)::value, R = Q ^ 1, b = decltype(bc)::value;
         f32x16 T2[2];
-        init_bias(T2[0], pack + OFF_E2, h, 63, 32);
-        init_bias(T2[1], pack + OFF_E2 + 32, h, 63, 32);
+        init_bias(T2[0], pack + OFF_E2, h, 63, 4);
+        init_bias(T2[1], pack + OFF_E2 + 32, h, 63, 4);
         for (int c = 0; c < 8; ++c) {
             f32x16 T1;
-            init_bias(T1, pack + OFF_E1 + c * 32, h, 255, 32);
-#pragma unroll
-            for (int it = 0; it < 4; ++it) mm<0, 16>(T1, S[b][it], pack + (long)(OFF_W1 + (c * 4 + it) * 16) * FR, lane);
-#pragma unroll
-            for (int ot = 0; ot < 2; ++ot) mm<0, 16>(T2[ot], T1, pack + (long)(OFF_W2 + (c * 2 + ot) * 16) * FR, lane);
+            init_bias(T1, pack + OFF_E1 + c * 32, h, 255, 4);
+            const int w1 = OFF_W1 + c * 64, w2 = OFF_W2 + c * 32;
+            pf<R, 16>(B, fptr(pack, w1 + 16), lane); mma<Q, 0, 16>(T1, S[b][0], B); MGX_FENCE();
+            pf<Q, 16>(B, fptr(pack, w1 + 32), lane); mma<R, 0, 16>(T1, S[b][1], B); MGX_FENCE();
+            pf<R, 16>(B, fptr(pack, w1 + 48), lane); mma<Q, 0, 16>(T1, S[b][2], B); MGX_FENCE();
+            pf<Q, 16>(B, fptr(pack, w2), lane);      mma<R, 0, 16>(T1, S[b][3], B); MGX_FENCE();
+            pf<R, 16>(B, fptr(pack, w2 + 16), lane); mma<Q, 0, 16>(T2[0], T1, B); MGX_FENCE();
+            pf<Q, 16>(B, c < 7 ? fptr(pack, w1 + 64) : fptr(pack, OFF_W3), lane);
+            mma<R, 0, 16>(T2[1], T1, B); MGX_FENCE();
         }
-        f32x16 T3;
-        init_bias(T3, pack + OFF_E3, h, 7, 8);
-        mm<0, 16>(T3, T2[0], pack + (long)(OFF_W3)*FR, lane);
-        mm<0, 16>(T3, T2[1], pack + (long)(OFF_W3 + 16) * FR, lane);
-        f32x16 O;
-        init_bias(O, pack + OFF_E4, h, 1, 2);
-        mm<0, 4>(O, T3, pack + (long)OFF_W4 * FR, lane);
+        f32x16 T3, O;
+        init_bias(T3, pack + OFF_E3, h, 7, 1);
+        init_bias(O, pack + OFF_E4, h, 7, 1);
+        pf<R, 16>(B, fptr(pack, OFF_W3 + 16), lane); mma<Q, 0, 16>(T3, T2[0], B); MGX_FENCE();
+        pf<Q, 4>(B, fptr(pack, OFF_W4), lane);       mma<R, 0, 16>(T3, T2[1], B); MGX_FENCE();
+        if (b == 0) pf<R, 16>(B, fptr(pack, OFF_W1), lane);
+        else if (!LAST) pf<R, 16>(B, after, lane);
+        mma<Q, 0, 4>(O, T3, B); MGX_FENCE();
         // rows 0,1 (the two output channels) live in registers 0,1 of lane half 0
-        if (pvalid && h == 0) {
-            float* dst = (A == 0 ? yrow0 : yrow1) + b * 2;
-            *(float2*)dst = make_float2(O[0], O[1]);
-        }
-    }
+        if (pvalid && h == 0) *(float2*)(yrow + b * 2) = make_float2(O[0], O[1]);
+    };
+    tail(std::integral_constant<int, P1>{}, std::integral_constant<int, 0>{});
+    tail(std::integral_constant<int, P0>{}, std::integral_constant<int, 1>{});
 }
 
-__global__ __launch_bounds__(256, 2) void gblock_fwd_kernel(const float* __restrict__ pack,
+__global__ __launch_bounds__(256, 1) void gblock_fwd_kernel(const float* __restrict__ pack,
                                                             const float* __restrict__ x, float* __restrict__ y,
                                                             long npix, int hl, int wl) {
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
@@ -217,8 +252,10 @@ __global__ __launch_bounds__(256, 2) void gblock_fwd_kernel(const float* __restr
     const int j = (int)(pc - row * wl);
     float* yrow0 = y + ((row * 2) * (2L * wl) + 2L * j) * 2;      // output row 2i,   column 2j
     float* yrow1 = yrow0 + (2L * wl) * 2;                         // output row 2i+1
-    half_block<0>(pack, x0, lane, h, pvalid, yrow0, yrow1);
-    half_block<1>(pack, x0, lane, h, pvalid, yrow0, yrow1);
+    WBuf B;
+    pf<0, 16>(B, fptr(pack, OFF_F), lane);
+    half_block<0, 0, false>(pack, x0, lane, h, pvalid, yrow0, B, fptr(pack, OFF_F));
+    half_block<1, 1, true>(pack, x0, lane, h, pvalid, yrow1, B, nullptr);
 }
 
 }  // namespace
