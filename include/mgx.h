@@ -157,16 +157,23 @@ int mgx_dense1_bwd(const float* dy, const float* x, const float* w, float* dx, f
                    int64_t n, int64_t e, void* stream);
 
 /* Losses (models.py:468-484) and the 6 metrics (models.py:128-130, 154-156).
- * mgx_logit_sums: sums[0] = sum(fake), sums[1] = sum(real) over n local logits (the pair that a
- *   data-parallel run all-reduces).
+ * mgx_logit_sums: sums[0] (+)= sum(fake), sums[1] (+)= sum(real) over n local logits (the pair that
+ *   a data-parallel run all-reduces; accumulate = 1 adds over micro-batches).
  * mgx_wgan_loss: from the GLOBAL sums and global batch n_global: ci, cu, sign = (cu-ci)/|cu-ci|
  *   (0 if equal); mode 0 = discriminator_loss, 1 = generator_loss; out[0]=loss, out[1]=cu,
  *   out[2]=ci, out[3]=|cu-ci|; dfake/dreal (n_local each, may be NULL) receive dloss/dlogit:
  *   mode 0: dreal = (sign+1e-4)/n_global, dfake = -(sign+9.99e-5)/n_global;
  *   mode 1: dfake = sign/n_global (sign treated as a constant). */
-int mgx_logit_sums(const float* fake, const float* real, int64_t n, float* sums, void* stream);
+int mgx_logit_sums(const float* fake, const float* real, int64_t n, float* sums, int accumulate, void* stream);
 int mgx_wgan_loss(const float* sums, int64_t n_global, int mode, float* out4,
                   float* dfake, float* dreal, int64_t n_local, void* stream);
+
+/* out = ca[0]*a + cb[0]*b (b, cb may be NULL): the loss gradients dloss/dlogit are uniform over the
+ * batch (see mgx_wgan_loss), so the step back-propagates unit seeds per micro-batch, separately for
+ * the fake and the real pass, and scales / combines the two flat gradient buffers here once the
+ * batch-wide sign is known.  ca, cb are device scalars (dfake[0], dreal[0] of mgx_wgan_loss). */
+int mgx_combine_grads(float* out, const float* a, const float* b, const float* ca, const float* cb, int64_t n,
+                      void* stream);
 
 /* Adam.apply_gradients with the hyper-parameters of models.py:502-503 (beta_1 = 0 so m == g):
  *   v = beta2*v + (1-beta2)*g*g;  p -= lr_t * g / (sqrt(v) + eps).

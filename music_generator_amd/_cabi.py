@@ -79,7 +79,8 @@ PROTOTYPES = {
     "mgx_softrect_bwd": (_I, [_P, _P, _P, _I, _I64, _F, _P]),
     "mgx_dense1_fwd": (_I, [_P, _P, _P, _P, _I64, _I64, _P]),
     "mgx_dense1_bwd": (_I, [_P, _P, _P, _P, _P, _P, _I64, _I64, _P]),
-    "mgx_logit_sums": (_I, [_P, _P, _I64, _P, _P]),
+    "mgx_logit_sums": (_I, [_P, _P, _I64, _P, _I, _P]),
+    "mgx_combine_grads": (_I, [_P, _P, _P, _P, _P, _I64, _P]),
     "mgx_wgan_loss": (_I, [_P, _I64, _I, _P, _P, _P, _I64, _P]),
     "mgx_adam_multi": (_I, [_P, _P, _P, _P, _P, _P, _P, _I64, _F, _F, _F, _P]),
 }

@@ -280,7 +280,7 @@ __global__ __launch_bounds__(kBlock) void dense1_bwd_kernel(const float* __restr
 
 // ---------------- losses ----------------
 __global__ __launch_bounds__(kBlock) void logit_sums_kernel(const float* __restrict__ fake, const float* __restrict__ real,
-                                                            long n, float* __restrict__ sums) {
+                                                            long n, float* __restrict__ sums, int accumulate) {
     __shared__ double red[4];
     double sf = 0.0, sr = 0.0;
     for (long i = threadIdx.x; i < n; i += kBlock) {
@@ -289,7 +289,19 @@ __global__ __launch_bounds__(kBlock) void logit_sums_kernel(const float* __restr
     }
     const double tf = block_sum256_d(sf, red);
     const double tr = block_sum256_d(sr, red);
-    if (threadIdx.x == 0) { sums[0] = (float)tf; sums[1] = (float)tr; }
+    if (threadIdx.x == 0) {
+        sums[0] = (float)(tf + (accumulate ? (double)sums[0] : 0.0));
+        sums[1] = (float)(tr + (accumulate ? (double)sums[1] : 0.0));
+    }
+}
+
+// out = ca[0]*a + cb[0]*b (b optional): combines gradients taken with unit logit seeds
+__global__ __launch_bounds__(kBlock) void combine_kernel(float* __restrict__ out, const float* __restrict__ a,
+                                                         const float* __restrict__ b, const float* __restrict__ ca,
+                                                         const float* __restrict__ cb, long n) {
+    const float fa = ca[0], fb = b ? cb[0] : 0.f;
+    for (long i = (long)blockIdx.x * kBlock + threadIdx.x; i < n; i += (long)gridDim.x * kBlock)
+        out[i] = b ? fa * a[i] + fb * b[i] : fa * a[i];
 }
 
 __global__ __launch_bounds__(kBlock) void wgan_loss_kernel(const float* __restrict__ sums, long n_global, int mode,
@@ -428,9 +440,21 @@ extern "C" int mgx_dense1_bwd(const float* dy, const float* x, const float* w, f
     return mgx_launch_status();
 }
 
-extern "C" int mgx_logit_sums(const float* fake, const float* real, int64_t n, float* sums, void* stream) {
+extern "C" int mgx_logit_sums(const float* fake, const float* real, int64_t n, float* sums, int accumulate,
+                              void* stream) {
     if (!sums || n <= 0 || (!fake && !real)) return MGX_ERR_ARG;
-    hipLaunchKernelGGL(logit_sums_kernel, dim3(1), dim3(kBlock), 0, (hipStream_t)stream, fake, real, (long)n, sums);
+    hipLaunchKernelGGL(logit_sums_kernel, dim3(1), dim3(kBlock), 0, (hipStream_t)stream, fake, real, (long)n, sums,
+                       accumulate);
+    return mgx_launch_status();
+}
+
+extern "C" int mgx_combine_grads(float* out, const float* a, const float* b, const float* ca, const float* cb,
+                                 int64_t n, void* stream) {
+    if (!out || !a || !ca || n <= 0 || (b && !cb)) return MGX_ERR_ARG;
+    long g = (n + kBlock - 1) / kBlock;
+    if (g > 2048) g = 2048;
+    hipLaunchKernelGGL(combine_kernel, dim3((unsigned)g), dim3(kBlock), 0, (hipStream_t)stream, out, a, b, ca, cb,
+                       (long)n);
     return mgx_launch_status();
 }
 

@@ -363,20 +363,28 @@ class Model:
             outs.append(self(x[i:i + bs]).cpu().numpy())
         return np.concatenate(outs, axis=0)
 
-    def bind_grads(self) -> torch.Tensor:
-        """Point every trainable variable's `.grad` at its slice of this model's flat gradient
-        buffer (allocated once) and return the flat buffer."""
-        if self._grad_flat is None:
+    def bind_grads(self, slot: int = 0) -> torch.Tensor:
+        """Point every trainable variable's `.grad` at its slice of flat gradient buffer `slot` of
+        this model (allocated once per slot, same layout) and return that buffer.  Slot 0 is the
+        one the optimiser reads; slot 1 holds the real-batch pass of the discriminator step."""
+        if self._grad_layout is None:
             layout, off = [], 0
             for v in self.trainable_variables:
                 n = v.size
                 layout.append((v, off, n))
                 off += (n + 3) & ~3           # keep every slice 16-byte aligned
             self._grad_layout = layout
-            self._grad_flat = K.zeros((max(off, 4),))
+            self._grad_size = max(off, 4)
+            self._grad_flats = {}
+        flat = self._grad_flats.get(slot)
+        if flat is None:
+            flat = K.zeros((self._grad_size,))
+            self._grad_flats[slot] = flat
+            if slot == 0:
+                self._grad_flat = flat
         for v, off, n in self._grad_layout:
-            v.grad = self._grad_flat[off:off + n]
-        return self._grad_flat
+            v.grad = flat[off:off + n]
+        return flat
 
     def grad_layout(self):
         if self._grad_layout is None:

@@ -398,6 +398,9 @@ class WGAN:
         self.train_steps = None
         self.dist = None                      # parallel.DataParallel when sharded over GPUs
         self.last_losses = None
+        self.micro_batch = None               # samples per micro-batch (multiple of 4); None = whole batch
+        self._mb_cache: Dict = {}
+        self._ones_cache: Dict = {}
         self._latents: List = []
         self._rng: Optional[torch.Generator] = None
         for model in (discriminator, generator):
@@ -431,20 +434,69 @@ class WGAN:
             return z.to(K.device(), torch.float32).contiguous()
         return torch.randn((n,) + tuple(self.latent_dim), dtype=torch.float32, device=K.device(), generator=self._rng)
 
-    def _logit_stats(self, fake_logits, real_logits, mode, n_local, want_seeds):
-        """sums -> (all-reduce) -> loss/metrics kernel.  Returns (out4, dfake, dreal)."""
-        sums, out4 = K.empty((2,)), K.empty((4,))
-        ops.logit_sums(fake_logits.view(-1), real_logits.view(-1), sums)
+    # -- micro-batching: whole MinibatchStdDev groups (members m, M+m, 2M+m, 3M+m), g-major --
+    def _micro_batches(self, n):
+        """Index tensors of the micro-batches of a local batch of n (None = the whole batch)."""
+        mb = self.micro_batch
+        if not mb or mb >= n:
+            return [None]
+        g = min(4, n)
+        if n % g or mb % g:
+            raise ValueError("batch %d / micro-batch %d must be multiples of the MinibatchStdDev group size %d"
+                             % (n, mb, g))
+        key = (n, mb)
+        if key not in self._mb_cache:
+            m, per = n // g, mb // g
+            out = []
+            for m0 in range(0, m, per):
+                groups = np.arange(m0, min(m0 + per, m))
+                idx = (np.arange(g)[:, None] * m + groups[None, :]).reshape(-1)
+                out.append(torch.as_tensor(idx, dtype=torch.int64, device=K.device()))
+            self._mb_cache[key] = out
+        return self._mb_cache[key]
+
+    @staticmethod
+    def _take(t, idx):
+        return t if idx is None else t.index_select(0, idx)
+
+    def _ones(self, n):
+        t = self._ones_cache.get(n)
+        if t is None:
+            t = torch.ones((n, 1), dtype=torch.float32, device=K.device())
+            self._ones_cache[n] = t
+        return t
+
+    def _finish_sums(self, sums, mode, n_local, want_coef):
+        """(all-reduce the logit sums) -> loss kernel.  Returns (out4, dfake[1], dreal[1]): the two
+        coefficients are d(loss)/d(logit), uniform over the batch (trainer/models.py:468-484)."""
         n_global = n_local
         if self.dist is not None:
             self.dist.all_reduce(sums)
             n_global = n_local * self.dist.world_size
-        dfake = K.empty((n_local, 1)) if want_seeds else None
-        dreal = K.empty((n_local, 1)) if (want_seeds and mode == 0) else None
-        ops.wgan_loss(sums, n_global, mode, out4, dfake, dreal, n_local if want_seeds else 0)
+        out4 = K.empty((4,))
+        dfake = K.empty((1,)) if want_coef else None
+        dreal = K.empty((1,)) if (want_coef and mode == 0) else None
+        ops.wgan_loss(sums, n_global, mode, out4, dfake, dreal, 1 if want_coef else 0)
         return out4, dfake, dreal
 
+    def _metric_block(self, real, n, batches):
+        """models.py:124-130 / 150-156: fresh latents, forward only."""
+        D, G = self.discriminator, self.generator
+        z = self._draw(n)
+        sums = K.zeros((2,))
+        for idx in batches:
+            fake_logits = D(G(self._take(z, idx)))
+            real_logits = D(self._take(real, idx))
+            ops.logit_sums(fake_logits.view(-1), real_logits.view(-1), sums, accumulate=True)
+        out4, _, _ = self._finish_sums(sums, 0, n, False)
+        return out4
+
     def train_step(self, real_images):
+        """One G+D step (trainer/models.py:72-158).  Because d(loss)/d(logit) is the same constant
+        for every fake (resp. real) sample, each micro-batch is back-propagated with unit seeds as
+        soon as it has been forwarded; the fake-pass and real-pass gradient sums are scaled by the
+        two constants once the batch-wide sign is known.  A step therefore costs the same number
+        of passes with or without micro-batching, and needs one micro-batch of activations."""
         if self.fade_in:
             if self.train_steps is None or self.train_steps < 2:
                 raise ValueError("fade-in needs set_train_steps(n) with n >= 2 (alpha = step/(n-1))")
@@ -458,47 +510,62 @@ class WGAN:
         D, G = self.discriminator, self.generator
         real = D._to_device(real_images)
         n = real.shape[0]
+        batches = self._micro_batches(n)
 
         # ---- discriminator update(s) ----
         for _ in range(self.d_steps):
             z = self._draw(n)
-            flat = D.bind_grads()
-            flat.zero_()
-            fake, _ = G.forward(z, save=False)
-            fake_logits, tape_f = D.forward(fake, save=True)
-            real_logits, tape_r = D.forward(real, save=True)
-            out_d, dfake, dreal = self._logit_stats(fake_logits, real_logits, 0, n, True)
-            D.backward(tape_f, dfake, need_input_grad=False)
-            D.backward(tape_r, dreal, need_input_grad=False)
-            del tape_f, tape_r, fake
+            flat_f = D.bind_grads(0)
+            flat_f.zero_()
+            flat_r = D.bind_grads(1)
+            flat_r.zero_()
+            sums = K.zeros((2,))
+            for idx in batches:
+                zb, rb = self._take(z, idx), self._take(real, idx)
+                ones = self._ones(rb.shape[0])
+                fake, _ = G.forward(zb, save=False)
+                fake_logits, tape = D.forward(fake, save=True)
+                del fake
+                D.bind_grads(0)
+                D.backward(tape, ones, need_input_grad=False)
+                real_logits, tape = D.forward(rb, save=True)
+                D.bind_grads(1)
+                D.backward(tape, ones, need_input_grad=False)
+                del tape
+                ops.logit_sums(fake_logits.view(-1), real_logits.view(-1), sums, accumulate=True)
+            out_d, cf, cr = self._finish_sums(sums, 0, n, True)
+            ops.combine_grads(flat_f, flat_f, flat_r, cf, cr)
             if self.dist is not None:
-                self.dist.all_reduce(flat)
+                self.dist.all_reduce(flat_f)
+            D.bind_grads(0)
             self.d_optimizer.apply_model_gradients(D)
 
         # ---- metric block 0 ----
-        fake_logits = D(G(self._draw(n)))
-        real_logits = D(real)
-        m0, _, _ = self._logit_stats(fake_logits, real_logits, 0, n, False)
+        m0 = self._metric_block(real, n, batches)
 
         # ---- generator update ----
         z = self._draw(n)
-        flat = G.bind_grads()
-        flat.zero_()
-        gen, tape_g = G.forward(z, save=True)
-        gen_logits, tape_d = D.forward(gen, save=True)
-        real_logits = D(real)
-        out_g, dgen_logits, _ = self._logit_stats(gen_logits, real_logits, 1, n, True)
-        dgen = D.backward(tape_d, dgen_logits, need_input_grad=True, need_weight_grads=False)
-        G.backward(tape_g, dgen, need_input_grad=False)
-        del tape_d, tape_g, gen, dgen
+        flat_g = G.bind_grads(0)
+        flat_g.zero_()
+        sums = K.zeros((2,))
+        for idx in batches:
+            zb, rb = self._take(z, idx), self._take(real, idx)
+            gen, tape_g = G.forward(zb, save=True)
+            gen_logits, tape_d = D.forward(gen, save=True)
+            del gen
+            dgen = D.backward(tape_d, self._ones(rb.shape[0]), need_input_grad=True, need_weight_grads=False)
+            G.backward(tape_g, dgen, need_input_grad=False)
+            del tape_d, tape_g, dgen
+            real_logits = D(rb)
+            ops.logit_sums(gen_logits.view(-1), real_logits.view(-1), sums, accumulate=True)
+        out_g, cf, _ = self._finish_sums(sums, 1, n, True)
+        ops.combine_grads(flat_g, flat_g, None, cf, None)
         if self.dist is not None:
-            self.dist.all_reduce(flat)
+            self.dist.all_reduce(flat_g)
         self.g_optimizer.apply_model_gradients(G)
 
         # ---- metric block 1 ----
-        fake_logits = D(G(self._draw(n)))
-        real_logits = D(real)
-        m1, _, _ = self._logit_stats(fake_logits, real_logits, 0, n, False)
+        m1 = self._metric_block(real, n, batches)
 
         self.actual_step += 1
         self.last_losses = {"d_loss": out_d[0], "g_loss": out_g[0]}

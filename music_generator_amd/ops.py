@@ -277,11 +277,18 @@ def dense1_bwd(dy, x, w, dx, dw, db, n, e):
           "mgx_dense1_bwd")
 
 
-def logit_sums(fake, real, sums):
+def logit_sums(fake, real, sums, accumulate=False):
     n = fake.numel() if fake is not None else real.numel()
     if sums.numel() != 2 or (fake is not None and real is not None and fake.numel() != real.numel()):
         raise MgxError("logit_sums: size mismatch")
-    check(_lib().mgx_logit_sums(_p(fake), _p(real), n, _p(sums), K.stream_ptr()), "mgx_logit_sums")
+    check(_lib().mgx_logit_sums(_p(fake), _p(real), n, _p(sums), int(accumulate), K.stream_ptr()), "mgx_logit_sums")
+
+
+def combine_grads(out, a, b, ca, cb):
+    n = out.numel()
+    if a.numel() != n or (b is not None and b.numel() != n) or ca.numel() != 1 or (cb is not None and cb.numel() != 1):
+        raise MgxError("combine_grads: size mismatch")
+    check(_lib().mgx_combine_grads(_p(out), _p(a), _p(b), _p(ca), _p(cb), n, K.stream_ptr()), "mgx_combine_grads")
 
 
 def wgan_loss(sums, n_global, mode, out4, dfake, dreal, n_local):

@@ -184,3 +184,34 @@ def test_two_consecutive_steps_fade_ramp():
         for key, val in res.metrics.items():
             assert abs(float(metrics[key]) - val) < (5e-5 if k == 0 else 5e-4), (k, key, float(metrics[key]), val)
     assert gan.actual_step == 2
+
+
+def test_micro_batching_reproduces_whole_batch_step():
+    """WGAN.micro_batch splits the batch by whole MinibatchStdDev groups; unit-seed gradients are
+    summed per micro-batch and scaled once the batch-wide sign is known, so the step must equal the
+    whole-batch step up to float32 summation order (gradients rel-L2 1e-5, metrics abs 1e-5)."""
+    n_blocks, stage, batch = 2, 1, 16
+    real, z4 = R.synthetic_inputs(stage, batch, seed=5)
+    results = []
+    for mb in (None, 4, 8):
+        d, g, comp, W = build(n_blocks)
+        gan = comp[stage][1]
+        gan.micro_batch = mb
+        gan.set_train_steps(11)
+        gan.actual_step = 3
+        gan.inject_latents(z4)
+        metrics = {k: float(v) for k, v in gan.train_step(real).items()}
+        grads = {}
+        for model in (gan.discriminator, gan.generator):
+            for v in model.trainable_variables:
+                grads[v.name] = v.grad.cpu().numpy().copy()
+        results.append((metrics, grads))
+    base_m, base_g = results[0]
+    for metrics, grads in results[1:]:
+        for k in base_m:
+            assert abs(metrics[k] - base_m[k]) < 1e-5, k
+        for k, v in base_g.items():
+            if np.abs(v).max() < 1e-12:
+                continue
+            tol = 1e-5 if not k.startswith(("dense_", "conv2d_transpose", "layer_norm", "weighted_sum_1")) else 2e-3
+            assert rel_l2(grads[k], v) < tol, "%s: %.3e" % (k, rel_l2(grads[k], v))
