@@ -189,7 +189,7 @@ def test_two_consecutive_steps_fade_ramp():
 def test_micro_batching_reproduces_whole_batch_step():
     """WGAN.micro_batch splits the batch by whole MinibatchStdDev groups; unit-seed gradients are
     summed per micro-batch and scaled once the batch-wide sign is known, so the step must equal the
-    whole-batch step up to float32 summation order (gradients rel-L2 1e-5, metrics abs 1e-5)."""
+    whole-batch step up to float32 summation order (D gradients rel-L2 5e-5, metrics abs 1e-5)."""
     n_blocks, stage, batch = 2, 1, 16
     real, z4 = R.synthetic_inputs(stage, batch, seed=5)
     results = []
@@ -213,5 +213,5 @@ def test_micro_batching_reproduces_whole_batch_step():
         for k, v in base_g.items():
             if np.abs(v).max() < 1e-12:
                 continue
-            tol = 1e-5 if not k.startswith(("dense_", "conv2d_transpose", "layer_norm", "weighted_sum_1")) else 2e-3
+            tol = 5e-5 if not k.startswith(("dense_", "conv2d_transpose", "layer_norm", "weighted_sum_1")) else 2e-3
             assert rel_l2(grads[k], v) < tol, "%s: %.3e" % (k, rel_l2(grads[k], v))

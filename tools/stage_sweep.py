@@ -1,0 +1,49 @@
+#!/usr/bin/env python3
+"""Per-stage G+D train-step throughput on one MI355X (fp32): the "samples/sec per progressive
+stage" table.  For each stage it runs `steps` timed steps of the straight-through twin (fade-in
+with --fade) on synthetic audio resident in HBM and prints one JSON line per stage.
+
+    python tools/stage_sweep.py [--stages 0,1,2,3,4,5] [--steps 2] [--fade]
+"""
+import argparse, json, os, sys, time
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, ROOT)
+import torch
+import music_generator_amd as M
+
+STEP_GFLOP = [13.6, 59.9, 245.0, 985.0, 3947.0, 15794.0, 63182.0]
+# (batch, micro_batch) per stage: large batches at low resolution, memory-bounded micro-batches above
+PLAN = {0: (256, None), 1: (256, None), 2: (128, None), 3: (64, None), 4: (32, 16), 5: (16, 4), 6: (4, 4)}
+
+ap = argparse.ArgumentParser()
+ap.add_argument("--stages", default="0,1,2,3,4,5")
+ap.add_argument("--steps", type=int, default=2)
+ap.add_argument("--fade", action="store_true")
+args = ap.parse_args()
+for stage in [int(s) for s in args.stages.split(",")]:
+    batch, mb = PLAN[stage]
+    M.clear_session()
+    torch.cuda.empty_cache()
+    torch.cuda.reset_peak_memory_stats()
+    d = M.define_discriminator(stage + 1)
+    g = M.define_generator(stage + 1)
+    fade = args.fade and stage > 0
+    gan = M.define_composite(d, g, (1, 100, 2))[stage][1 if fade else 0]
+    gan.micro_batch = mb
+    gan.set_train_steps(100)
+    h, w = 4 << stage, 750 << stage
+    real = torch.rand((batch, h, w, 2), device="cuda") * 2 - 1
+    gan.train_step(real)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(args.steps):
+        m = gan.train_step(real)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / args.steps
+    print(json.dumps({"stage": stage, "hw": [h, w], "batch": batch, "micro_batch": mb, "fade_in": fade,
+                      "ms_per_step": round(dt * 1e3, 2), "samples_per_s": round(batch / dt, 3),
+                      "algorithmic_tflops": round(STEP_GFLOP[stage] * batch / dt / 1e3, 2),
+                      "frac_f32_mfma_peak": round(STEP_GFLOP[stage] * batch / dt / 1e3 / 157.3, 4),
+                      "peak_hbm_gib": round(torch.cuda.max_memory_allocated() / 2**30, 1),
+                      "delta_1": float(m["delta_1"])}), flush=True)
+    del gan, d, g, real
