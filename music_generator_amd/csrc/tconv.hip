@@ -1,5 +1,6 @@
-// LDS-staged tile kernels for the discriminator's stride-1 'same' convolutions (3x3 and 2x2,
-// 32-channel chunks) on v_mfma_f32_32x32x2_f32: forward, data-gradient and weight-gradient.
+// LDS-staged tile kernel for the WEIGHT gradient of the discriminator's stride-1 'same'
+// convolutions (3x3 and 2x2, 32-channel chunks) on v_mfma_f32_32x32x2_f32, plus the dispatch
+// predicates shared with the forward / data-gradient tile kernel (tconv3.hip).
 //
 // A workgroup (4 waves) walks output tiles of TH=8 rows x TW=32 columns of one image.  The input
 // tile with its halo ((8+kh-1) x (32+kw-1) positions x 32 channels) is staged once into LDS with a
@@ -87,98 +88,6 @@ __device__ __forceinline__ void stage_tile(float* lds, int pstr, const float* __
                 if (MUL) val *= m[j];
                 if (!ok[j]) val = (f32x4){0.f, 0.f, 0.f, 0.f};
                 if (px < NPIX) *(f32x4*)(lds + px * pstr + c4 * 4) = val;
-            }
-        }
-    }
-}
-
-// ------------------------------------------------------------------------------------------
-// forward / data-gradient
-// ------------------------------------------------------------------------------------------
-template <int KH, int KW, bool WT>   // WT: weights stored [n][k] (wsk == 1, wsn == 32); else [k][n] (wsk == 32, wsn == 1)
-__global__ __launch_bounds__(256, 2) void tconv_kernel(mgx_conv_desc d, const float* __restrict__ x,
-                                                       const float* __restrict__ xmul, const float* __restrict__ w,
-                                                       const float* __restrict__ bias, float* __restrict__ y,
-                                                       float* __restrict__ dact, long ntiles, int tiles_h,
-                                                       int tiles_w) {
-    extern __shared__ __attribute__((aligned(16))) float lds[];
-    constexpr int IH = TH + KH - 1, IW = TW + KW - 1, TAPS = KH * KW;
-    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
-    const int r = lane & 31, h = lane >> 5;
-    const int H = d.hin, W = d.win;
-    const int kchunks = d.cin / 32, nchunks = d.ngemm / 32;
-    const bool reload_w = (kchunks * nchunks) > 1;
-    const float inv_alpha = d.act_alpha > 0.f ? 1.0f / d.act_alpha : 0.f;
-    float wreg[TAPS][16];
-    bool w_loaded = false;
-
-    for (long t = blockIdx.x; t < ntiles; t += gridDim.x) {
-        const Tile q = decode_tile(t, tiles_h, tiles_w);
-        for (int nc = 0; nc < nchunks; ++nc) {
-            f32x16 acc[2];
-#pragma unroll
-            for (int i = 0; i < 16; ++i) { acc[0][i] = 0.f; acc[1][i] = 0.f; }
-            for (int kc = 0; kc < kchunks; ++kc) {
-                __syncthreads();  // every wave is done reading the previous contents
-                if (nc == 0 || kchunks > 1) {
-                    if (xmul) stage_tile<IH, IW, true>(lds, PSTR, x, xmul, q.img, q.h0 - d.pt, q.w0 - d.pl, H, W, d.cin, kc * 32);
-                    else stage_tile<IH, IW, false>(lds, PSTR, x, xmul, q.img, q.h0 - d.pt, q.w0 - d.pl, H, W, d.cin, kc * 32);
-                }
-                if (reload_w || !w_loaded) {
-#pragma unroll
-                    for (int tap = 0; tap < TAPS; ++tap) {
-                        const int wt = d.flip ? (TAPS - 1 - tap) : tap;
-                        constexpr int WSK = WT ? 1 : 32, WSN = WT ? 32 : 1;   // compile-time strides: one
-                        const float* wp = w + (long)wt * d.wtap + (kc * 32 + 16 * h) * WSK +   // base address,
-                                          (nc * 32 + r) * WSN;                                  // immediate offsets
-#pragma unroll
-                        for (int s = 0; s < 16; ++s) wreg[tap][s] = wp[s * WSK];
-                    }
-                    w_loaded = true;
-                }
-                __syncthreads();
-                // (tile row, tap) steps in a fixed, fully unrolled order.  The scheduling barrier after
-                // each step keeps the compiler from hoisting the LDS reads of later steps to the top
-                // (the register file holds the weights); the second wave of the SIMD covers the wait.
-                const float* base = lds + ((wv * 2) * IW + r) * PSTR + 16 * h;
-                static_for<0, 2 * TAPS>([&](auto step_c) {
-                    constexpr int step = decltype(step_c)::value;
-                    constexpr int pt = step / TAPS, tap = step % TAPS;
-                    const float* src = base + ((pt + tap / KW) * IW + (tap % KW)) * PSTR;
-                    f32x4 cur[4];
-#pragma unroll
-                    for (int j = 0; j < 4; ++j) cur[j] = *(const f32x4*)(src + 4 * j);
-#pragma unroll
-                    for (int j = 0; j < 4; ++j)
-#pragma unroll
-                        for (int s = 0; s < 4; ++s) acc[pt] = mfma32(cur[j][s], wreg[tap][4 * j + s], acc[pt]);
-                    __builtin_amdgcn_sched_barrier(0);
-                });
-            }
-            // ---- epilogue for output channels [nc*32, nc*32+32) ----
-            const int n = nc * 32 + r;
-            const float bv = d.nbias > 0 ? bias[n] : 0.f;
-#pragma unroll
-            for (int pt = 0; pt < 2; ++pt) {
-                const int hh = q.h0 + wv * 2 + pt;
-                const long rowoff = ((q.img * H + hh) * (long)W) * d.ngemm + n;
-#pragma unroll
-                for (int reg = 0; reg < 16; ++reg) {
-                    const int col = q.w0 + acc_row(reg, lane);
-                    if (col >= W) continue;
-                    const long off = rowoff + (long)col * d.ngemm;
-                    float v = acc[pt][reg] + bv;
-                    if (d.act_alpha > 0.f) {
-                        float tt, s2;
-                        tanh_sech2(v, tt, s2);
-                        if (dact) dact[off] = s2 + inv_alpha;
-                        v = tt + v / d.act_alpha;
-                    }
-                    if (d.accumulate) v += y[off];
-                    y[off] = v;
-                    // bound the live ranges of the unrolled epilogue (the weights stay in registers)
-                    if ((reg & 3) == 3) __builtin_amdgcn_sched_barrier(0);
-                }
             }
         }
     }
@@ -274,19 +183,12 @@ bool mgx_tconv_applicable(const mgx_conv_desc& d) {
     return true;
 }
 
+int mgx_tconv3_launch(const mgx_conv_desc& d, const float* x, const float* xmul, const float* w, const float* bias,
+                      float* y, float* dact, hipStream_t st);
+
 int mgx_tconv_launch(const mgx_conv_desc& d, const float* x, const float* xmul, const float* w, const float* bias,
                      float* y, float* dact, hipStream_t st) {
-    const int tiles_h = d.hin / TH, tiles_w = (d.win + TW - 1) / TW;
-    const long ntiles = (long)d.nimg * tiles_h * tiles_w;
-    dim3 grid(tile_grid(ntiles)), block(256);
-    constexpr int lds3 = tconv_lds_bytes<3, 3>(), lds2 = tconv_lds_bytes<2, 2>();
-    const bool wt = d.wsk == 1;
-#define MGX_TC(KK, WW, LDS) \
-    hipLaunchKernelGGL((tconv_kernel<KK, KK, WW>), grid, block, LDS, st, d, x, xmul, w, bias, y, dact, ntiles, tiles_h, tiles_w)
-    if (d.kh == 3) { if (wt) MGX_TC(3, true, lds3); else MGX_TC(3, false, lds3); }
-    else { if (wt) MGX_TC(2, true, lds2); else MGX_TC(2, false, lds2); }
-#undef MGX_TC
-    return mgx_launch_status();
+    return mgx_tconv3_launch(d, x, xmul, w, bias, y, dact, st);   // tconv3.hip
 }
 
 // weight gradient: same applicability on the FORWARD descriptor, output channels must be 32

@@ -1,0 +1,222 @@
+// Stride-1 'same' convolution (3x3 / 2x2) of one 32-channel input slice into one 32-channel
+// output slice on v_mfma_f32_32x32x2_f32 — forward and data-gradient of the discriminator convs.
+//
+// One workgroup of 8 waves per CU walks tiles of 8 rows x 32 columns; wave w owns row w (one
+// 32x32 accumulator tile).  LDS holds
+//   * the 32x32 weight slice of every tap, once per launch, as [tap][k/4][n][4] so that a lane
+//     (column n, half h) fetches four consecutive k with one conflict-free ds_read_b128;
+//   * two input tiles with halo ((8+kh-1) x (32+kw-1) positions x 32 channels, 36-float stride):
+//     while the MFMAs run on one, the next tile's global loads are already in flight into
+//     registers (issued before the compute phase) and are written to the other buffer after it,
+//     so HBM/L2 latency hides under the matrix work; one barrier per tile.
+// The two waves that share a SIMD drift apart between barriers, which overlaps one wave's
+// epilogue (bias, tanh(x)+x/alpha, stores) with the other's MFMAs.  Register use stays far below
+// the 256 a 2-waves-per-SIMD kernel may use: no spills, no scratch traffic.
+// Convs with 128 input (output) channels take 4 steps per tile over 32-channel slices: the
+// accumulator persists over input slices (output slices re-use the staged tile); the next
+// slice's weights travel through registers like the next tile and replace the LDS copy between
+// two barriers.
+#include "common.h"
+#include "../../include/mgx.h"
+
+namespace {
+
+constexpr int TH = 8, TW = 32, PSTR = 36;
+
+template <int KH, int KW>
+constexpr int lds_floats() { return KH * KW * 1024 + 2 * (TH + KH - 1) * (TW + KW - 1) * PSTR; }
+
+template <int KH, int KW, bool WT, bool MUL>
+__global__ __launch_bounds__(512, 2) void tconv3_kernel(mgx_conv_desc d, const float* __restrict__ x,
+                                                        const float* __restrict__ xmul,
+                                                        const float* __restrict__ w,
+                                                        const float* __restrict__ bias, float* __restrict__ y,
+                                                        float* __restrict__ dact, long ntiles, int tiles_h,
+                                                        int tiles_w) {
+    extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr int IH = TH + KH - 1, IW = TW + KW - 1, TAPS = KH * KW, NPIX = IH * IW;
+    constexpr int SITER = (NPIX * 8 + 511) / 512;      // float4 staging loads per thread (input tile)
+    constexpr int WITER = (TAPS * 256 + 511) / 512;    // float4 staging stores per thread (weights)
+    float* wl = lds;                                   // [TAPS][8][32][4]
+    float* xt = lds + TAPS * 1024;                     // [2][NPIX][36]
+    const int tid = threadIdx.x;
+    const int lane = tid & 63, wv = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const int H = d.hin, W = d.win;
+    const int kchunks = d.cin / 32, nchunks = d.ngemm / 32;     // one of them is 1
+    const int S = kchunks * nchunks;                            // steps per tile
+
+    // ---- weight slice (kc, nc) of every tap: global -> registers -> LDS ----
+    f32x4 wreg[WITER];
+    auto w_load = [&](int oc) {
+        const int kc = kchunks > 1 ? oc : 0, nc = nchunks > 1 ? oc : 0;
+        const long woff = (long)kc * 32 * d.wsk + (long)nc * 32 * d.wsn;
+#pragma unroll
+        for (int it = 0; it < WITER; ++it) {
+            const int i = min(tid + 512 * it, TAPS * 256 - 1);
+            const int tap = i >> 8, kq = (i >> 5) & 7, n = i & 31;
+            const int wt = d.flip ? (TAPS - 1 - tap) : tap;
+            const float* wp = w + (long)wt * d.wtap + woff;
+            if (WT) wreg[it] = *(const f32x4*)(wp + n * 32 + kq * 4);          // [n][k], rows of 32
+            else {
+#pragma unroll
+                for (int j = 0; j < 4; ++j) wreg[it][j] = wp[(kq * 4 + j) * 32 + n];   // [k][n], rows of 32
+            }
+        }
+    };
+    auto w_write = [&]() {
+#pragma unroll
+        for (int it = 0; it < WITER; ++it) {
+            const int i = tid + 512 * it;
+            if (i < TAPS * 256) *(f32x4*)(wl + i * 4) = wreg[it];
+        }
+    };
+
+    // ---- input tile: thread t moves float4 #(t + 512 i), i < SITER ----
+    const int c4 = tid & 7;
+    auto tile_of = [&](long t, long& img, int& h0, int& w0) {
+        const int per_img = tiles_h * tiles_w;
+        img = t / per_img;
+        const int rem = (int)(t - img * per_img);
+        const int th = rem / tiles_w;
+        h0 = th * TH;
+        w0 = (rem - th * tiles_w) * TW;
+    };
+    f32x4 sv[SITER], sm[SITER];
+    bool sok[SITER];
+    auto stage_load = [&](long t, int kc) {
+        long img; int h0, w0;
+        tile_of(t, img, h0, w0);
+#pragma unroll
+        for (int i = 0; i < SITER; ++i) {
+            const int px = (tid >> 3) + 64 * i;
+            const int ty = px / IW, tx = px - ty * IW;
+            const int hi = h0 - d.pt + ty, wi = w0 - d.pl + tx;
+            sok[i] = px < NPIX && hi >= 0 && hi < H && wi >= 0 && wi < W;
+            const int hc = min(max(hi, 0), H - 1), wc = min(max(wi, 0), W - 1);
+            const long off = ((img * H + hc) * W + wc) * (long)d.cin + kc * 32 + c4 * 4;
+            sv[i] = *(const f32x4*)(x + off);
+            if (MUL) sm[i] = *(const f32x4*)(xmul + off);
+        }
+    };
+    auto stage_write = [&](float* buf) {
+#pragma unroll
+        for (int i = 0; i < SITER; ++i) {
+            const int px = (tid >> 3) + 64 * i;
+            f32x4 v = sv[i];
+            if (MUL) v *= sm[i];
+            if (!sok[i]) v = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if (px < NPIX) *(f32x4*)(buf + px * PSTR + c4 * 4) = v;
+        }
+    };
+
+    long t = blockIdx.x;
+    int oc = 0;
+    w_load(0);
+    w_write();
+    if (t < ntiles) {
+        stage_load(t, 0);
+        stage_write(xt);
+    }
+    __syncthreads();
+    const float inv_alpha = d.act_alpha > 0.f ? 1.0f / d.act_alpha : 0.f;
+    int cur = 0;
+    f32x16 acc;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    while (t < ntiles) {
+        // the step after this one: next output/input chunk of the same tile, or the next tile
+        int ocn = oc + 1;
+        long tn = t;
+        if (ocn == S) { ocn = 0; tn = t + gridDim.x; }
+        const bool has_next = tn < ntiles;
+        const bool need_x = has_next && (kchunks > 1 || ocn == 0);
+        const bool need_w = has_next && S > 1;
+        if (need_x) stage_load(tn, kchunks > 1 ? ocn : 0);     // in flight during the MFMA phase
+        if (need_w) w_load(ocn);
+        const float* xb = xt + cur * (NPIX * PSTR);
+#pragma unroll
+        for (int ta = 0; ta < KH; ++ta)
+#pragma unroll
+            for (int tb = 0; tb < KW; ++tb) {
+                const float* asrc = xb + ((wv + ta) * IW + (r + tb)) * PSTR + 16 * h;
+                const float* wsrc = wl + ((ta * KW + tb) * 8 + 4 * h) * 128 + r * 4;
+#pragma unroll
+                for (int j = 0; j < 4; ++j) {
+                    const f32x4 av = *(const f32x4*)(asrc + 4 * j);
+                    const f32x4 wv4 = *(const f32x4*)(wsrc + j * 128);
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) acc = mfma32(av[s], wv4[s], acc);
+                }
+            }
+        if (kchunks == 1 || oc == S - 1) {
+            // ---- epilogue: row wv of the tile, output channels [32 nc, 32 nc + 32) ----
+            const int n = (nchunks > 1 ? oc : 0) * 32 + r;
+            const float bv = d.nbias > 0 ? bias[n] : 0.f;
+            long img; int h0, w0;
+            tile_of(t, img, h0, w0);
+            const long rowoff = ((img * H + h0 + wv) * (long)W + w0) * d.ngemm + n;
+            float* __restrict__ yrow = y + rowoff;
+            float* __restrict__ drow = dact ? dact + rowoff : nullptr;
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                const int cl = acc_row(reg, lane);
+                if (w0 + cl < W) {
+                    const int off = cl * d.ngemm;
+                    float v = acc[reg] + bv;
+                    if (d.act_alpha > 0.f) {
+                        float tt, s2;
+                        tanh_sech2(v, tt, s2);
+                        if (drow) drow[off] = s2 + inv_alpha;
+                        v = tt + v * inv_alpha;
+                    }
+                    if (d.accumulate) v += yrow[off];
+                    yrow[off] = v;
+                }
+                acc[reg] = 0.f;
+            }
+        }
+        if (S > 1) __syncthreads();        // every wave is done with the weight slice
+        if (need_x) stage_write(xt + (cur ^ 1) * (NPIX * PSTR));
+        if (need_w) w_write();
+        __syncthreads();
+        if (need_x) cur ^= 1;
+        t = tn;
+        oc = ocn;
+    }
+}
+
+template <int KH, int KW>
+void launch3(const mgx_conv_desc& d, const float* x, const float* xmul, const float* w, const float* bias, float* y,
+             float* dact, hipStream_t st) {
+    const int tiles_h = d.hin / TH, tiles_w = (d.win + TW - 1) / TW;
+    const long ntiles = (long)d.nimg * tiles_h * tiles_w;
+    const unsigned grid = (unsigned)(ntiles < 256 ? ntiles : 256);
+    constexpr int lds = lds_floats<KH, KW>() * 4;
+    const bool wt = d.wsk == 1, mul = xmul != nullptr;
+    // more than 64 KiB of dynamic LDS must be allowed per kernel function
+#define MGX_T3(WW, MM)                                                                                               \
+    do {                                                                                                             \
+        static bool allowed = false;                                                                                 \
+        if (!allowed) {                                                                                              \
+            (void)hipFuncSetAttribute((const void*)tconv3_kernel<KH, KW, WW, MM>,                                      \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, lds);                              \
+            allowed = true;                                                                                          \
+        }                                                                                                            \
+        hipLaunchKernelGGL((tconv3_kernel<KH, KW, WW, MM>), dim3(grid), dim3(512), lds, st, d, x, xmul, w, bias, y,   \
+                           dact, ntiles, tiles_h, tiles_w);                                                          \
+    } while (0)
+    if (wt) { if (mul) MGX_T3(true, true); else MGX_T3(true, false); }
+    else { if (mul) MGX_T3(false, true); else MGX_T3(false, false); }
+#undef MGX_T3
+}
+
+}  // namespace
+
+// Runs the convolution described by d; applicability is checked by mgx_tconv_applicable (tconv.hip).
+int mgx_tconv3_launch(const mgx_conv_desc& d, const float* x, const float* xmul, const float* w, const float* bias,
+                      float* y, float* dact, hipStream_t st) {
+    if (d.kh == 3) launch3<3, 3>(d, x, xmul, w, bias, y, dact, st);
+    else launch3<2, 2>(d, x, xmul, w, bias, y, dact, st);
+    return mgx_launch_status();
+}
