@@ -194,6 +194,11 @@ int mgx_tconv_launch(const mgx_conv_desc& d, const float* x, const float* xmul, 
 // weight gradient: same applicability on the FORWARD descriptor, output channels must be 32
 bool mgx_twgrad_applicable(const mgx_conv_desc& d) { return mgx_tconv_applicable(d) && d.ngemm == 32 && d.flip == 0; }
 
+extern "C" int mgx_conv_route(const mgx_conv_desc* d, int wgrad) {
+    if (!d) return 0;
+    return (wgrad ? mgx_twgrad_applicable(*d) : mgx_tconv_applicable(*d)) ? 1 : 0;
+}
+
 long mgx_twgrad_splits(const mgx_conv_desc& d) {
     const int tiles_h = d.hin / TH, tiles_w = (d.win + TW - 1) / TW;
     return (long)tile_grid((long)d.nimg * tiles_h * tiles_w) * 4;

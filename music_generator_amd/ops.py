@@ -55,13 +55,18 @@ class LaunchProfiler:
 PROFILER: Optional[LaunchProfiler] = None
 
 
-def _gemm_key(d: ConvDesc) -> str:
+def _gemm_key(d: ConvDesc, mul: bool = False) -> str:
+    if _lib().mgx_conv_route(C.byref(d), 0):
+        return "tconv3_kernel<%d,%d,%s,%s>" % (d.kh, d.kw, "true" if d.wsk == 1 else "false",
+                                               "true" if mul else "false")
     nt = (d.ngemm + 31) // 32
     pn = "4,1" if nt == 1 else ("2,2" if nt == 2 else "2,4")
     return "conv_gemm_kernel<%s,%d,%s>" % (pn, 0 if d.wsn == 1 else 1, "true" if d.cin % 8 == 0 else "false")
 
 
 def _wgrad_key(d: ConvDesc) -> str:
+    if _lib().mgx_conv_route(C.byref(d), 1):
+        return "twgrad_kernel<%d,%d>" % (d.kh, d.kw)
     taps, kt, nt = d.kh * d.kw, (d.cin + 31) // 32, (d.ngemm + 31) // 32
     if taps % 9 == 0:
         return "wgrad_kernel<9,1,1>"
@@ -111,7 +116,7 @@ def conv_gemm(d: ConvDesc, x, w, bias, y, xmul=None, dact=None, accumulate=False
     check(_lib().mgx_conv_gemm_f32(C.byref(d), _p(x), _p(xmul), _p(w), _p(bias) if d.nbias else None,
                                    _p(y), _p(dact), K.stream_ptr()), "mgx_conv_gemm_f32")
     if e0 is not None:
-        PROFILER.stop(_gemm_key(d), _conv_flops(d), e0)
+        PROFILER.stop(_gemm_key(d, xmul is not None), _conv_flops(d), e0)
 
 
 def conv_wgrad(d: ConvDesc, x, dy, dw, dbias, dymul=None):

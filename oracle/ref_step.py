@@ -593,6 +593,30 @@ def train_step(weights: Dict[str, np.ndarray], n_blocks: int, stage: int, fade_i
     return res
 
 
+def generator_step_grads(weights: Dict[str, np.ndarray], n_blocks: int, stage: int, fade_in: bool,
+                         real: np.ndarray, z: np.ndarray, trainable_alpha: bool = True, dtype=torch.float64):
+    """Gradients of generator_loss w.r.t. the generator's trainable variables for the given
+    weights (models.py:133-144), e.g. with the discriminator weights a device run produced after
+    its D update: isolates the generator-step arithmetic from the sign-like first Adam step."""
+    names = layer_names(n_blocks)
+    W = {k: torch.tensor(np.asarray(v), dtype=dtype) for k, v in weights.items()}
+    fade = bool(fade_in and stage > 0)
+    g_names = trainable_names(names, stage, fade, "g")
+    if not trainable_alpha:
+        g_names = [n for n in g_names if not n.endswith("/alpha")]
+    for n in g_names:
+        W[n] = W[n].detach().requires_grad_(True)
+    ga = W[names["g"][stage]["ws"] + "/alpha"] if fade else None
+    da = W[names["d"][stage]["ws"] + "/alpha"] if fade else None
+    gen = generator(W, names, stage, fade, torch.tensor(z, dtype=dtype), ga)
+    gen_logits = discriminator(W, names, stage, fade, gen, da)
+    with torch.no_grad():
+        real_logits = discriminator(W, names, stage, fade, torch.tensor(real, dtype=dtype), da)
+    loss = generator_loss(gen_logits, real_logits)
+    grads = torch.autograd.grad(loss, [W[n] for n in g_names])
+    return {n: g.detach().numpy().copy() for n, g in zip(g_names, grads)}
+
+
 def synthetic_inputs(stage: int, batch: int, seed: int = 0):
     """real ~ U(-1,1) (N,H,W,2) and four latent draws ~ N(0,1) (N,1,100,2), float32, from
     numpy default_rng(seed) / default_rng(seed+1..seed+4)."""

@@ -6,12 +6,16 @@ Stated tolerances (float32 device arithmetic vs float64 oracle):
   logits                abs 2e-5
   generated audio       max abs 1e-4 (post-LayerNorm, O(1))
   D-step gradients      rel-L2 5e-5 per tensor on the stored checksum vector (measured 2e-6..3e-5;
-                        the worst is the scalar Dense(1) bias, a cancelling sum of the two seeds)
-  G-step gradients      rel-L2 2e-3: they are taken AFTER the discriminator's Adam update, whose
-                        first step is sign-like (beta_1 = 0), so float32-level differences of
-                        near-zero D gradients move single D weights by up to ~1e-4; the saturated
-                        output tanh turns the resulting logit shift into a common factor
-                        exp(-2*dx) on every generator gradient (measured 2e-5..7e-4)
+                        the worst is the scalar Dense(1) bias, a cancelling sum of the two seeds);
+                        5e-4 for the scalar fade-in alpha (see d_grad_tol)
+  G-step gradients      vs the golden fixture rel-L2 2e-2: they are taken AFTER the discriminator's
+                        Adam update, whose first step is sign-like (beta_1 = 0), so float32-level
+                        differences of near-zero D gradients move single D weights by up to ~1e-4;
+                        the saturated output tanh turns the resulting logit shift dx into a factor
+                        exp(-2*dx) on the generator gradients (measured 2e-5..5e-3).  The arithmetic
+                        of the generator step itself is pinned separately at rel-L2 1e-4 by
+                        test_generator_step_with_device_discriminator, which hands the device's
+                        own post-update discriminator weights to the oracle.
                         (abs 1e-9 for tensors whose gradient is numerically zero)
   updated weights       abs 2e-5 on elements whose gradient is not within 1e-3 of the tensor's
                         rms (Adam with beta_1 = 0 is sign-like on its first step, so a 1-ulp sign
@@ -47,6 +51,12 @@ def summarize(a, k=64):
     a = np.asarray(a, dtype=np.float64).reshape(-1)
     idx = np.linspace(0, a.size - 1, num=min(k, a.size)).astype(np.int64)
     return np.concatenate([[a.sum(), np.sqrt((a * a).sum())], a[idx]])
+
+
+def d_grad_tol(name):
+    """rel-L2 bound of a D-step gradient tensor: 5e-5, and 5e-4 for the scalar fade-in alpha, whose
+    gradient sum(dY * (new - old)) over the whole activation cancels to ~1e-3 of its terms."""
+    return 5e-4 if name.endswith("/alpha") else 5e-5
 
 
 def build(n_blocks, trainable_alpha=True, seed=100):
@@ -103,7 +113,7 @@ def test_train_step_matches_golden(name):
             if np.abs(want).max() < 1e-12:
                 assert np.abs(have).max() < 1e-9, v.name
             else:
-                tol = 5e-5 if prefix == "dgrad|" else 2e-3
+                tol = d_grad_tol(v.name) if prefix == "dgrad|" else 2e-2
                 err = rel_l2(have[2:], want[2:])
                 assert err < tol, "%s%s: rel-L2 %.3e" % (prefix, v.name, err)
                 assert abs(have[1] - want[1]) <= tol * want[1] + 1e-12, v.name
@@ -137,8 +147,35 @@ def test_train_step_matches_oracle_directly():
             if np.abs(want).max() < 1e-12:
                 assert np.abs(have).max() < 1e-9, v.name
             else:
-                tol = 5e-5 if model is gan.discriminator else 2e-3
+                tol = d_grad_tol(v.name) if model is gan.discriminator else 2e-2
                 assert rel_l2(have, want) < tol, "%s: %.3e" % (v.name, rel_l2(have, want))
+
+
+@pytest.mark.parametrize("name", ["s0_n4", "s1_straight_n4", "s1_fade_a037_n4", "s2_fade_a037_n4"])
+def test_generator_step_with_device_discriminator(name):
+    """Generator-step gradients against the oracle evaluated with the discriminator weights the
+    device produced in its own D update (the generator update does not touch them): rel-L2 1e-4,
+    and 5e-4 for biases and the scalar alpha (per-channel / global sums over the whole activation
+    in front of a LayerNormalization, which removes most of a constant shift: the sums cancel to a
+    small fraction of their terms, measured up to 1.6e-4)."""
+    n_blocks, stage, fade, batch, ks, tr_alpha = CASES[name]
+    gan, metrics, fake = device_step(name)
+    W = R.synthetic_weights(n_blocks, seed=100)
+    for v in gan.discriminator.trainable_variables:
+        W[v.name] = v.numpy()
+    if ks:
+        names = R.layer_names(n_blocks)
+        W[names["g"][stage]["ws"] + "/alpha"] = np.asarray(ks[0] / float(ks[1] - 1), np.float32)
+    real, z4 = R.synthetic_inputs(stage, batch, seed=0)
+    want = R.generator_step_grads(W, n_blocks, stage, fade, real, z4[2], trainable_alpha=tr_alpha)
+    for v in gan.generator.trainable_variables:
+        have = v.grad.cpu().numpy().reshape(v.shape)
+        if np.abs(want[v.name]).max() < 1e-12:
+            assert np.abs(have).max() < 1e-9, v.name
+        else:
+            err = rel_l2(have, want[v.name])
+            tol = 5e-4 if v.name.endswith(("/bias", "/alpha", "/beta")) else 1e-4
+            assert err < tol, "%s: %.3e" % (v.name, err)
 
 
 @pytest.mark.parametrize("stage,fade", [(0, False), (2, False), (2, True)])
