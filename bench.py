@@ -48,6 +48,21 @@ def cpu_baseline(stage, fade, sample_batch, n_blocks):
                       % (stage, "fade-in" if fade else "straight", sample_batch, dt)}
 
 
+def measured_traffic(kernel, stage, fade, batch):
+    """HBM bytes per launch of `kernel` from the committed PMC passes (profiles/pmc_traffic.json:
+    2 x FETCH_SIZE + WRITE_SIZE of separate rocprofv3 --pmc runs of this same command), or None
+    when no pass for this workload and kernel is on file."""
+    path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    try:
+        with open(path) as f:
+            table = json.load(f)
+    except (OSError, ValueError):
+        return None
+    wl = table.get("stage%d_%s_b%d" % (stage, "fade" if fade else "straight", batch), {})
+    entry = wl.get(kernel)
+    return entry["hbm_bytes_per_launch"] if entry else None
+
+
 def main():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -123,11 +138,14 @@ def main():
     global_batch = args.batch * world
     value = global_batch * args.steps / elapsed
     summ = prof.summary()
-    key, (launches, ms, flops) = max(summ.items(), key=lambda kv: kv[1][1])
+    key, (launches, ms, flops, nbytes) = max(summ.items(), key=lambda kv: kv[1][1])
     achieved = flops / (ms * 1e-3) / 1e12
     contraction_ms = sum(v[1] for v in summ.values())
     roofline = {"bound": "mfma", "kernel": key, "achieved": round(achieved, 2), "peak": F32_MFMA_PEAK_TFLOPS,
-                "unit": "TFLOP/s", "frac": round(achieved / F32_MFMA_PEAK_TFLOPS, 4), "traffic": None,
+                "unit": "TFLOP/s", "frac": round(achieved / F32_MFMA_PEAK_TFLOPS, 4),
+                "traffic": measured_traffic(key, stage, fade, args.batch),
+                "algorithmic_gflop_per_launch": round(flops / launches / 1e9, 2),
+                "algorithmic_bytes_per_launch": round(nbytes / launches),
                 "launches": launches, "avg_launch_ms": round(ms / launches, 4),
                 "share_of_step_time": round(ms / args.steps / ms_per_step, 3),
                 "all_contractions_share_of_step_time": round(contraction_ms / args.steps / ms_per_step, 3),

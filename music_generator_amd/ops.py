@@ -38,17 +38,17 @@ class LaunchProfiler:
         e.record()
         return e
 
-    def stop(self, key, flops, e0):
+    def stop(self, key, flops, e0, nbytes=0.0):
         e1 = torch.cuda.Event(enable_timing=True)
         e1.record()
-        self.records.append((key, flops, e0, e1))
+        self.records.append((key, flops, e0, e1, nbytes))
 
     def summary(self):
-        """{key: (launches, total_ms, total_flops)} — call after torch.cuda.synchronize()."""
+        """{key: (launches, total_ms, total_flops, total_bytes)} — call after torch.cuda.synchronize()."""
         out = {}
-        for key, flops, e0, e1 in self.records:
-            n, ms, fl = out.get(key, (0, 0.0, 0.0))
-            out[key] = (n + 1, ms + e0.elapsed_time(e1), fl + flops)
+        for key, flops, e0, e1, nbytes in self.records:
+            n, ms, fl, by = out.get(key, (0, 0.0, 0.0, 0.0))
+            out[key] = (n + 1, ms + e0.elapsed_time(e1), fl + flops, by + nbytes)
         return out
 
 
@@ -80,6 +80,13 @@ def _wgrad_key(d: ConvDesc) -> str:
 def _conv_flops(d: ConvDesc) -> float:
     """Algorithmic FLOPs of the contraction: 2 * rows * taps * cin * ngemm."""
     return 2.0 * d.nimg * d.hout * d.wout * d.kh * d.kw * d.cin * d.ngemm
+
+
+def _conv_bytes(d: ConvDesc, n_in: int = 1, n_out: int = 1) -> float:
+    """Algorithmic HBM bytes of one contraction launch: every input-shaped operand read once,
+    every output-shaped operand written once, the weights once."""
+    xe, ye, we = _conv_sizes(d)
+    return 4.0 * (n_in * xe + n_out * ye + we + d.nbias)
 
 
 def make_conv_desc(**kw) -> ConvDesc:
@@ -116,7 +123,9 @@ def conv_gemm(d: ConvDesc, x, w, bias, y, xmul=None, dact=None, accumulate=False
     check(_lib().mgx_conv_gemm_f32(C.byref(d), _p(x), _p(xmul), _p(w), _p(bias) if d.nbias else None,
                                    _p(y), _p(dact), K.stream_ptr()), "mgx_conv_gemm_f32")
     if e0 is not None:
-        PROFILER.stop(_gemm_key(d, xmul is not None), _conv_flops(d), e0)
+        PROFILER.stop(_gemm_key(d, xmul is not None), _conv_flops(d), e0,
+                      _conv_bytes(d, 2 if xmul is not None else 1,
+                                  (2 if dact is not None else 1) + (1 if accumulate else 0)))
 
 
 def conv_wgrad(d: ConvDesc, x, dy, dw, dbias, dymul=None):
@@ -136,7 +145,7 @@ def conv_wgrad(d: ConvDesc, x, dy, dw, dbias, dymul=None):
     check(lib.mgx_conv_wgrad_f32(C.byref(d), _p(x), _p(dy), _p(dymul), _p(dw), _p(dbias),
                                  ws.data_ptr(), ws.numel(), K.stream_ptr()), "mgx_conv_wgrad_f32")
     if e0 is not None:
-        PROFILER.stop(_wgrad_key(d), _conv_flops(d), e0)
+        PROFILER.stop(_wgrad_key(d), _conv_flops(d), e0, _conv_bytes(d, 1, 2 if dymul is not None else 1))
 
 
 def gblock_pack_floats() -> int:
