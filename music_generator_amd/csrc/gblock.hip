@@ -12,6 +12,8 @@
 // loop (both sub-columns b share the branch prefix); the 128-wide featured tensor is recomputed
 // per branch (16 MFMAs) instead of being held in registers.
 #include "common.h"
+#include "gblock_frag.h"
+#include "gblock_rows.h"
 #include "../../include/mgx.h"
 
 #include <type_traits>
@@ -19,7 +21,6 @@
 namespace {
 
 // fragment offsets (units of 64 floats)
-constexpr int FR = 64;
 constexpr int OFF_F = 0;                 // featured conv: [ot 4][tap 4]
 constexpr int OFF_BR = 16;               // 6 branches x 264
 constexpr int BR_FR = 264;
@@ -41,8 +42,6 @@ constexpr int OFF_E2 = OFF_E1 + 256;
 constexpr int OFF_E3 = OFF_E2 + 64;
 constexpr int OFF_E4 = OFF_E3 + 8;
 constexpr int PACK_FLOATS = OFF_E4 + 8;
-
-__device__ __forceinline__ int chan(int s, int h) { return (s & 3) + 8 * (s >> 2) + 4 * h; }
 
 // ------------------------------------------------------------------------------------------
 // pack: one thread per packed float
@@ -114,27 +113,6 @@ __global__ __launch_bounds__(256) void gblock_pack_kernel(mgx_gblock_weights w, 
 // from buffer P, the fragments of the next group are loaded into buffer P^1 (their L2 latency is
 // covered by the 16 x 64 cycles of the running group).  Buffer parities are compile-time: every
 // rolled loop body holds an even number of groups.
-struct WBuf {
-    float v[2][16];
-};
-
-template <int P, int NS>
-__device__ __forceinline__ void pf(WBuf& B, const float* __restrict__ frag, int lane) {
-#pragma unroll
-    for (int s = 0; s < NS; ++s) B.v[P][s] = frag[s * FR + lane];
-}
-
-// acc += sum_{s < NS} B.v[P][s] (A operand: weights) x tile[S0 + s] (B operand: activations)
-template <int P, int S0, int NS>
-__device__ __forceinline__ void mma(f32x16& acc, const f32x16& tile, const WBuf& B) {
-#pragma unroll
-    for (int s = 0; s < NS; ++s) acc = mfma32(B.v[P][s], tile[S0 + s], acc);
-}
-
-#define MGX_FENCE() __builtin_amdgcn_sched_barrier(0)
-
-__device__ __forceinline__ const float* fptr(const float* pack, int frag) { return pack + (long)frag * FR; }
-
 // accumulator tile initialised with bias rows c(reg,h): registers 4g..4g+3 are the 4 consecutive
 // rows 8g+4h.. (one 16-byte load each); groups g >= ngroups start at zero
 __device__ __forceinline__ void init_bias(f32x16& acc, const float* __restrict__ bias, int h, int mask, int ngroups) {
@@ -149,9 +127,14 @@ __device__ __forceinline__ void init_bias(f32x16& acc, const float* __restrict__
 
 // One sub-row A of the 2x2 output block, both sub-columns.  On entry buffer PS holds the 16
 // featured-conv fragments; on exit buffer PS^1 holds the 16 fragments at `after` (if LAST is false).
-template <int A, int PS, bool LAST>
+// With SAVE every intermediate tensor a weight gradient needs is written to the wave's tile of the
+// activation buffer `act` (row map: gblock_rows.h); stores are placed behind the MFMAs of the
+// following group so that they do not wait on the matrix pipeline.
+template <int A, int PS, bool LAST, bool SAVE>
 __device__ __forceinline__ void half_block(const float* __restrict__ pack, float x0, int lane, int h, bool pvalid,
-                                           float* __restrict__ yrow, WBuf& B, const float* __restrict__ after) {
+                                           float* __restrict__ yrow, WBuf& B, const float* __restrict__ after,
+                                           float* __restrict__ act) {
+    const int r = lane & 31;
     constexpr int P0 = PS, P1 = PS ^ 1;
     f32x16 S[2][4];
 #pragma unroll
@@ -169,6 +152,11 @@ __device__ __forceinline__ void half_block(const float* __restrict__ pack, float
 #pragma unroll
         for (int tap = 0; tap < 4; ++tap) F[it] = mfma32(B.v[P0][it * 4 + tap], x0, F[it]);
     MGX_FENCE();
+    if (SAVE && A == 0) {
+        act[(GB_X + h) * 32 + r] = x0;
+#pragma unroll
+        for (int it = 0; it < 4; ++it) save_rows<16>(act, GB_F + it * 32, F[it], r, h);
+    }
 
     // six branches (26 groups each); every branch adds D2_k * o3_k into S, its bias is in bsum
     for (int k = 0; k < 6; ++k) {
@@ -182,19 +170,27 @@ __device__ __forceinline__ void half_block(const float* __restrict__ pack, float
         pf<P1, 4>(B, fptr(pack, bf + BR_D1), lane);       mma<P0, 0, 16>(o1, F[3], B); MGX_FENCE();
         // Dense(32) on the 16 channels of sub-row A: registers 8A..8A+7 of o1
         init_bias(o2, bb + 16, h, 31, 4);
-        pf<P0, 4>(B, fptr(pack, bf + BR_D1 + 4), lane);   mma<P1, 8 * A, 4>(o2, o1, B); MGX_FENCE();
+        float* abr = act + (GB_BR + k * GB_BR_ROWS) * 32;
+        pf<P0, 4>(B, fptr(pack, bf + BR_D1 + 4), lane);   mma<P1, 8 * A, 4>(o2, o1, B);
+        if (SAVE && A == 0) save_rows<16>(abr, GB_O1, o1, r, h);
+        MGX_FENCE();
         pf<P1, 16>(B, fptr(pack, bf + BR_K2), lane);      mma<P0, 8 * A + 4, 4>(o2, o1, B); MGX_FENCE();
 #pragma unroll
         for (int b = 0; b < 2; ++b) {
             f32x16 o3[2];
             init_bias(o3[0], bb + 48, h, 63, 4);
             init_bias(o3[1], bb + 80, h, 63, 4);
-            pf<P0, 16>(B, fptr(pack, bf + BR_K2 + (b * 2 + 1) * 16), lane); mma<P1, 0, 16>(o3[0], o2, B); MGX_FENCE();
+            pf<P0, 16>(B, fptr(pack, bf + BR_K2 + (b * 2 + 1) * 16), lane); mma<P1, 0, 16>(o3[0], o2, B);
+            if (SAVE && b == 0) save_rows<16>(abr, GB_O2 + A * 32, o2, r, h);
+            MGX_FENCE();
             pf<P1, 16>(B, fptr(pack, bf + BR_D2), lane);                    mma<P0, 0, 16>(o3[1], o2, B); MGX_FENCE();
 #pragma unroll
             for (int g = 0; g < 8; g += 2) {       // D2 groups g = ot*2 + it
                 pf<P0, 16>(B, fptr(pack, bf + BR_D2 + (g + 1) * 16), lane);
-                mma<P1, 0, 16>(S[b][g / 2], o3[0], B); MGX_FENCE();
+                mma<P1, 0, 16>(S[b][g / 2], o3[0], B);
+                if (SAVE && g == 0) save_rows<16>(abr, GB_O3 + (A * 2 + b) * 64, o3[0], r, h);
+                if (SAVE && g == 2) save_rows<16>(abr, GB_O3 + (A * 2 + b) * 64 + 32, o3[1], r, h);
+                MGX_FENCE();
                 const float* nxt;
                 if (g < 6) nxt = fptr(pack, bf + BR_D2 + (g + 2) * 16);
                 else if (b == 0) nxt = fptr(pack, bf + BR_K2 + 32);
@@ -204,6 +200,12 @@ __device__ __forceinline__ void half_block(const float* __restrict__ pack, float
             }
         }
     }
+    if (SAVE) {
+#pragma unroll
+        for (int b = 0; b < 2; ++b)
+#pragma unroll
+            for (int ot = 0; ot < 4; ++ot) save_rows<16>(act, GB_S + (A * 2 + b) * 128 + ot * 32, S[b][ot], r, h);
+    }
     // tail (51 groups per sub-column): Dense(256) in 8 chunks of 32 rows, each chunk immediately consumed by
     // Dense(64); then Dense(8), Dense(2).  Entry: buffer Q holds W1 chunk 0 / input tile 0.
     auto tail = [&](auto qc, auto bc) {
@@ -211,6 +213,7 @@ __device__ __forceinline__ void half_block(const float* __restrict__ pack, float
         f32x16 T2[2];
         init_bias(T2[0], pack + OFF_E2, h, 63, 4);
         init_bias(T2[1], pack + OFF_E2 + 32, h, 63, 4);
+        constexpr int ab = A * 2 + b;
         for (int c = 0; c < 8; ++c) {
             f32x16 T1;
             init_bias(T1, pack + OFF_E1 + c * 32, h, 255, 4);
@@ -221,16 +224,25 @@ __device__ __forceinline__ void half_block(const float* __restrict__ pack, float
             pf<Q, 16>(B, fptr(pack, w2), lane);      mma<R, 0, 16>(T1, S[b][3], B); MGX_FENCE();
             pf<R, 16>(B, fptr(pack, w2 + 16), lane); mma<Q, 0, 16>(T2[0], T1, B); MGX_FENCE();
             pf<Q, 16>(B, c < 7 ? fptr(pack, w1 + 64) : fptr(pack, OFF_W3), lane);
-            mma<R, 0, 16>(T2[1], T1, B); MGX_FENCE();
+            mma<R, 0, 16>(T2[1], T1, B);
+            if (SAVE) save_rows<16>(act, GB_T1 + ab * 256 + c * 32, T1, r, h);
+            MGX_FENCE();
         }
         f32x16 T3, O;
         init_bias(T3, pack + OFF_E3, h, 7, 1);
         init_bias(O, pack + OFF_E4, h, 7, 1);
         pf<R, 16>(B, fptr(pack, OFF_W3 + 16), lane); mma<Q, 0, 16>(T3, T2[0], B); MGX_FENCE();
-        pf<Q, 4>(B, fptr(pack, OFF_W4), lane);       mma<R, 0, 16>(T3, T2[1], B); MGX_FENCE();
+        pf<Q, 4>(B, fptr(pack, OFF_W4), lane);       mma<R, 0, 16>(T3, T2[1], B);
+        if (SAVE) {
+            save_rows<16>(act, GB_T2 + ab * 64, T2[0], r, h);
+            save_rows<16>(act, GB_T2 + ab * 64 + 32, T2[1], r, h);
+        }
+        MGX_FENCE();
         if (b == 0) pf<R, 16>(B, fptr(pack, OFF_W1), lane);
         else if (!LAST) pf<R, 16>(B, after, lane);
-        mma<Q, 0, 4>(O, T3, B); MGX_FENCE();
+        mma<Q, 0, 4>(O, T3, B);
+        if (SAVE) save_rows<4>(act, GB_T3 + ab * 8, T3, r, h);
+        MGX_FENCE();
         // rows 0,1 (the two output channels) live in registers 0,1 of lane half 0
         if (pvalid && h == 0) *(float2*)(yrow + b * 2) = make_float2(O[0], O[1]);
     };
@@ -238,32 +250,41 @@ __device__ __forceinline__ void half_block(const float* __restrict__ pack, float
     tail(std::integral_constant<int, P0>{}, std::integral_constant<int, 1>{});
 }
 
+template <bool SAVE>
 __global__ __launch_bounds__(256, 1) void gblock_fwd_kernel(const float* __restrict__ pack,
                                                             const float* __restrict__ x, float* __restrict__ y,
-                                                            long npix, int hl, int wl) {
+                                                            float* __restrict__ act, long npix, int hl, int wl) {
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int r = lane & 31, h = lane >> 5;
     const long p = ((long)blockIdx.x * 4 + wv) * 32 + r;
     const bool pvalid = p < npix;
     const long pc = pvalid ? p : 0;
     // B operand of the featured conv: lane (position r, half h) supplies channel h of its position
-    const float x0 = x[pc * 2 + h];
+    // positions past the end contribute activations of a zero input; their gradients are zero
+    const float x0 = pvalid ? x[pc * 2 + h] : 0.f;
+    float* atile = SAVE ? act + ((long)blockIdx.x * 4 + wv) * (GB_ROWS * 32L) : nullptr;
     const long row = pc / wl;                 // n*hl + i
     const int j = (int)(pc - row * wl);
     float* yrow0 = y + ((row * 2) * (2L * wl) + 2L * j) * 2;      // output row 2i,   column 2j
     float* yrow1 = yrow0 + (2L * wl) * 2;                         // output row 2i+1
     WBuf B;
     pf<0, 16>(B, fptr(pack, OFF_F), lane);
-    half_block<0, 0, false>(pack, x0, lane, h, pvalid, yrow0, B, fptr(pack, OFF_F));
-    half_block<1, 1, true>(pack, x0, lane, h, pvalid, yrow1, B, nullptr);
+    half_block<0, 0, false, SAVE>(pack, x0, lane, h, pvalid, yrow0, B, fptr(pack, OFF_F), atile);
+    half_block<1, 1, true, SAVE>(pack, x0, lane, h, pvalid, yrow1, B, nullptr, atile);
 }
 
 }  // namespace
 
 extern "C" int64_t mgx_gblock_pack_floats(void) { return PACK_FLOATS; }
 
-extern "C" int mgx_gblock_fwd_f32(const mgx_gblock_weights* wp, float* pack, const float* x, float* y, int64_t nimg,
-                                  int hl, int wl, void* stream) {
+extern "C" int64_t mgx_gblock_side_floats(int64_t nimg, int hl, int wl) {
+    if (nimg <= 0 || hl <= 0 || wl <= 0) return 0;
+    const long npix = (long)nimg * hl * wl;
+    return ((npix + 127) / 128) * 4 * (GB_ROWS * 32L);
+}
+
+extern "C" int mgx_gblock_fwd_f32(const mgx_gblock_weights* wp, float* pack, const float* x, float* y, float* act,
+                                  int64_t nimg, int hl, int wl, void* stream) {
     if (!wp || !pack || !x || !y || nimg <= 0 || hl <= 0 || wl <= 0) return MGX_ERR_ARG;
     const mgx_gblock_weights w = *wp;
     const void* const* ptrs = (const void* const*)&w;
@@ -274,6 +295,11 @@ extern "C" int mgx_gblock_fwd_f32(const mgx_gblock_weights* wp, float* pack, con
     const long npix = (long)nimg * hl * wl;
     const long blocks = (npix + 127) / 128;
     if (blocks > 0x7fffffffL) return MGX_ERR_ARG;
-    hipLaunchKernelGGL(gblock_fwd_kernel, dim3((unsigned)blocks), dim3(256), 0, st, pack, x, y, npix, hl, wl);
+    if (act)
+        hipLaunchKernelGGL(gblock_fwd_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, st, pack, x, y, act, npix, hl,
+                           wl);
+    else
+        hipLaunchKernelGGL(gblock_fwd_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, st, pack, x, y, act, npix,
+                           hl, wl);
     return mgx_launch_status();
 }

@@ -1,0 +1,543 @@
+// Backward of one generator grow block (add_generator_block, trainer/models.py:358-399; the
+// tf.GradientTape sweep of models.py:144-146) in three steps:
+//   1. gblock_dgrad_kernel: the data-gradient chain dY -> dX of all 26 linear layers in registers
+//      (same transposed, register-chained MFMA scheme as the forward kernel, with the weight
+//      fragments packed "input row x output channel"); every intermediate gradient a weight
+//      gradient needs is written to the tile-major gradient buffer (row map: gblock_rows.h).
+//   2. gblock_wgrad_kernel<TA,TB>: dW[ci][co] = sum over positions of act[ci][p] * grad[co][p]
+//      for a table of (activation rows, gradient rows) jobs.  Both buffers hold 32 positions per
+//      row, so a lane reads 16 bytes = 4 contraction steps of its channel: operands go straight
+//      from L2/HBM to the MFMA, no LDS.  A wave keeps TA x TB accumulator tiles for its share of
+//      the position tiles and writes one slab; bias gradients are per-lane sums of the gradient
+//      operand.
+//   3. gblock_unpack_kernel: one thread per weight / bias element adds the slabs in split order
+//      (bitwise reproducible) into the Keras-layout gradient tensors.
+#include "common.h"
+#include "gblock_frag.h"
+#include "gblock_rows.h"
+#include "../../include/mgx.h"
+
+#include <type_traits>
+
+namespace {
+
+// ------------------------------------------------------------------------------------------
+// transposed weight fragments (units of 64 floats)
+// ------------------------------------------------------------------------------------------
+constexpr int PT_W43 = 0;                 // 16 slots: [0] W4, [1..4] W3 rows 0-31, [5..8] W3 rows 32-63, rest 0
+constexpr int PT_W2 = 16;                 // [c 8][it 2][s 16]
+constexpr int PT_W1 = PT_W2 + 256;        // [c 8][ot 4][s 16]
+constexpr int PT_BR = PT_W1 + 512;        // 6 branches x PBR
+constexpr int PBR = 272;
+constexpr int PB_D2 = 0;                  // [ot 2][it 4][s 16]
+constexpr int PB_K2 = 128;                // [b 2][it 2][s 16]
+constexpr int PB_D1 = 192;                // [s 16], rows >= 16 zero
+constexpr int PB_K1 = 208;                // [a 2][ot 4][s 8]
+constexpr int PT_K0 = PT_BR + 6 * PBR;    // [it 4][s 16], rows >= 2 zero, the four taps summed
+constexpr int PT_FRAGS = PT_K0 + 64;
+constexpr int PACKT_FLOATS = PT_FRAGS * FR;
+
+// A-operand fragment of step s for lane (i, h): W[input row i][output channel chan(s, h)]
+__global__ __launch_bounds__(256) void gblock_packT_kernel(mgx_gblock_weights w, float* __restrict__ packT) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= PACKT_FLOATS) return;
+    const int fr = idx / FR, lane = idx % FR;
+    const int i = lane & 31, h = lane >> 5;
+    float v = 0.f;
+    if (fr < PT_W2) {
+        if (fr == 0) v = i < 8 ? w.w4[i * 2 + h] : 0.f;                       // W4 (8,2)
+        else if (fr <= 8) {                                                   // W3 (64,8)
+            const int ot = (fr - 1) / 4, s = (fr - 1) % 4;
+            v = w.w3[(32 * ot + i) * 8 + s + 4 * h];
+        }
+    } else if (fr < PT_W1) {                                                  // W2 (256,64)
+        const int g = fr - PT_W2;
+        const int c = g / 32, it = (g % 32) / 16, s = g % 16;
+        v = w.w2[(32 * c + i) * 64 + 32 * it + chan(s, h)];
+    } else if (fr < PT_BR) {                                                  // W1 (128,256)
+        const int g = fr - PT_W1;
+        const int c = g / 64, ot = (g % 64) / 16, s = g % 16;
+        v = w.w1[(32 * ot + i) * 256 + 32 * c + chan(s, h)];
+    } else if (fr < PT_K0) {
+        const int k = (fr - PT_BR) / PBR, f = (fr - PT_BR) % PBR;
+        if (f < PB_K2) {                                                      // D2 (64,128)
+            const int ot = f / 64, it = (f % 64) / 16, s = f % 16;
+            v = w.d2[k][(32 * ot + i) * 128 + 32 * it + chan(s, h)];
+        } else if (f < PB_D1) {                                               // K2 (1,2,64,32): [b][co][ci]
+            const int g = f - PB_K2;
+            const int b = g / 32, it = (g % 32) / 16, s = g % 16;
+            v = w.k2[k][(b * 64 + 32 * it + chan(s, h)) * 32 + i];
+        } else if (f < PB_K1) {                                               // D1 (16,32)
+            const int s = f - PB_D1;
+            v = i < 16 ? w.d1[k][i * 32 + chan(s, h)] : 0.f;
+        } else {                                                              // K1 (2,1,16,128): [a][co][ci]
+            const int g = f - PB_K1;
+            const int a = g / 32, ot = (g % 32) / 8, s = g % 8;
+            v = w.k1[k][(a * 16 + chan(s, h)) * 128 + 32 * ot + i];
+        }
+    } else {                                                                  // K0 (2,2,2,128): [tap][c][n]
+        const int g = fr - PT_K0;
+        const int it = g / 16, s = g % 16;
+        if (i < 2)
+            for (int tap = 0; tap < 4; ++tap) v += w.k0[(tap * 2 + i) * 128 + 32 * it + chan(s, h)];
+    }
+    packT[idx] = v;
+}
+
+__device__ __forceinline__ void zero(f32x16& t) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) t[i] = 0.f;
+}
+
+// ------------------------------------------------------------------------------------------
+// data gradient.  A wave owns 32 low-resolution positions; sub-row a is the (rolled) outer loop.
+// Per a: the tail chain of both sub-columns (50 fragment groups each), then per branch 23 groups
+// (D2 and K2 transposed for both sub-columns, D1, K1).  Buffer parities are compile-time: the
+// branch body is instantiated for both entry parities and the branch loop runs two per trip.
+// ------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256, 1) void gblock_dgrad_kernel(const float* __restrict__ packT,
+                                                              const float* __restrict__ dy,
+                                                              float* __restrict__ delta, float* __restrict__ dx,
+                                                              long npix, int hl, int wl) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const long tile = (long)blockIdx.x * 4 + wv;
+    const long p = tile * 32 + r;
+    const bool pvalid = p < npix;
+    const long pc = pvalid ? p : 0;
+    const long row = pc / wl;                 // n*hl + i
+    const int j = (int)(pc - row * wl);
+    const float* dy0 = dy + ((row * 2) * (2L * wl) + 2L * j) * 2 + h;     // output row 2i, column 2j, channel h
+    float* dt = delta + tile * (GB_ROWS * 32L);
+    WBuf B;
+    f32x16 dF[4];
+#pragma unroll
+    for (int it = 0; it < 4; ++it) zero(dF[it]);
+    pf<0, 16>(B, fptr(packT, PT_W43), lane);
+
+    for (int a = 0; a < 2; ++a) {
+        f32x16 dS[2][4];
+        // ---- tail: dY -> dT3 -> dT2 -> {dT1_c -> dS} for both sub-columns ----
+#pragma unroll
+        for (int b = 0; b < 2; ++b) {
+            const int ab = a * 2 + b;
+            const float o = pvalid ? dy0[(a * (2L * wl) + b) * 2] : 0.f;
+            f32x16 dT3, dT2[2];
+            zero(dT3); zero(dT2[0]); zero(dT2[1]);
+            pf<1, 4>(B, fptr(packT, PT_W43 + 5), lane);
+            dT3 = mfma32(B.v[0][0], o, dT3);
+#pragma unroll
+            for (int s = 0; s < 4; ++s) dT2[0] = mfma32(B.v[0][1 + s], dT3[s], dT2[0]);
+            MGX_FENCE();
+            pf<0, 16>(B, fptr(packT, PT_W2), lane);
+#pragma unroll
+            for (int s = 0; s < 4; ++s) dT2[1] = mfma32(B.v[1][s], dT3[s], dT2[1]);
+            dt[(GB_X + ab * 2 + h) * 32 + r] = o;
+            save_rows<4>(dt, GB_T3 + ab * 8, dT3, r, h);
+            MGX_FENCE();
+#pragma unroll
+            for (int ot = 0; ot < 4; ++ot) zero(dS[b][ot]);
+            for (int c = 0; c < 8; ++c) {
+                f32x16 dT1;
+                zero(dT1);
+                const int w2 = PT_W2 + c * 32, w1 = PT_W1 + c * 64;
+                pf<1, 16>(B, fptr(packT, w2 + 16), lane); mma<0, 0, 16>(dT1, dT2[0], B); MGX_FENCE();
+                pf<0, 16>(B, fptr(packT, w1), lane);      mma<1, 0, 16>(dT1, dT2[1], B); MGX_FENCE();
+                pf<1, 16>(B, fptr(packT, w1 + 16), lane); mma<0, 0, 16>(dS[b][0], dT1, B); MGX_FENCE();
+                pf<0, 16>(B, fptr(packT, w1 + 32), lane); mma<1, 0, 16>(dS[b][1], dT1, B); MGX_FENCE();
+                pf<1, 16>(B, fptr(packT, w1 + 48), lane); mma<0, 0, 16>(dS[b][2], dT1, B); MGX_FENCE();
+                const float* nxt = c < 7 ? fptr(packT, w2 + 32) : (b == 0 ? fptr(packT, PT_W43) : fptr(packT, PT_BR));
+                pf<0, 16>(B, nxt, lane);
+                mma<1, 0, 16>(dS[b][3], dT1, B);
+                save_rows<16>(dt, GB_T1 + ab * 256 + c * 32, dT1, r, h);
+                MGX_FENCE();
+            }
+            save_rows<16>(dt, GB_T2 + ab * 64, dT2[0], r, h);
+            save_rows<16>(dt, GB_T2 + ab * 64 + 32, dT2[1], r, h);
+#pragma unroll
+            for (int ot = 0; ot < 4; ++ot) save_rows<16>(dt, GB_S + ab * 128 + ot * 32, dS[b][ot], r, h);
+        }
+        // ---- branches ----
+        auto branch = [&](auto qc, int k) {
+            constexpr int Q = decltype(qc)::value, R = Q ^ 1;
+            const int bf = PT_BR + k * PBR;
+            float* dbr = dt + (GB_BR + k * GB_BR_ROWS) * 32;
+            f32x16 do2;
+            zero(do2);
+#pragma unroll
+            for (int b = 0; b < 2; ++b) {
+                f32x16 do3[2];
+                zero(do3[0]); zero(do3[1]);
+                // do3 = D2 dS: 8 groups (ot, it); entry: buffer Q holds group 0
+#pragma unroll
+                for (int g = 0; g < 8; g += 2) {
+                    pf<R, 16>(B, fptr(packT, bf + PB_D2 + (g + 1) * 16), lane);
+                    mma<Q, 0, 16>(do3[g / 4], dS[b][g % 4], B); MGX_FENCE();
+                    pf<Q, 16>(B, fptr(packT, g < 6 ? bf + PB_D2 + (g + 2) * 16 : bf + PB_K2 + b * 32), lane);
+                    mma<R, 0, 16>(do3[g / 4], dS[b][g % 4 + 1], B); MGX_FENCE();
+                }
+                // do2 += K2[b]^T do3
+                pf<R, 16>(B, fptr(packT, bf + PB_K2 + b * 32 + 16), lane); mma<Q, 0, 16>(do2, do3[0], B); MGX_FENCE();
+                pf<Q, 16>(B, fptr(packT, b == 0 ? bf + PB_D2 : bf + PB_D1), lane);
+                mma<R, 0, 16>(do2, do3[1], B);
+                save_rows<16>(dbr, GB_O3 + (a * 2 + b) * 64, do3[0], r, h);
+                save_rows<16>(dbr, GB_O3 + (a * 2 + b) * 64 + 32, do3[1], r, h);
+                MGX_FENCE();
+            }
+            // do1 = D1 do2 (rows < 16), dF += K1[a]^T do1 (8 steps per output tile)
+            f32x16 do1;
+            zero(do1);
+            pf<R, 16>(B, fptr(packT, bf + PB_K1 + a * 32), lane);
+            mma<Q, 0, 16>(do1, do2, B);
+            save_rows<16>(dbr, GB_O2 + a * 32, do2, r, h);
+            MGX_FENCE();
+            pf<Q, 16>(B, fptr(packT, bf + PB_K1 + a * 32 + 16), lane);
+            mma<R, 0, 8>(dF[0], do1, B);
+#pragma unroll
+            for (int s = 0; s < 8; ++s) dF[1] = mfma32(B.v[R][8 + s], do1[s], dF[1]);
+            save_rows<8>(dbr, GB_O1 + a * 16, do1, r, h);
+            MGX_FENCE();
+            const float* nxt = k < 5 ? fptr(packT, bf + PBR) : (a == 0 ? fptr(packT, PT_W43) : fptr(packT, PT_K0));
+            pf<R, 16>(B, nxt, lane);
+            mma<Q, 0, 8>(dF[2], do1, B);
+#pragma unroll
+            for (int s = 0; s < 8; ++s) dF[3] = mfma32(B.v[Q][8 + s], do1[s], dF[3]);
+            MGX_FENCE();
+        };
+        for (int k = 0; k < 6; k += 2) {
+            branch(std::integral_constant<int, 0>{}, k);
+            branch(std::integral_constant<int, 1>{}, k + 1);
+        }
+    }
+    // ---- dX = (sum of the four taps of K0)^T dF; the up-sampling backward is that tap sum ----
+#pragma unroll
+    for (int it = 0; it < 4; ++it) save_rows<16>(dt, GB_F + it * 32, dF[it], r, h);
+    f32x16 dxa;
+    zero(dxa);
+    pf<1, 16>(B, fptr(packT, PT_K0 + 16), lane); mma<0, 0, 16>(dxa, dF[0], B); MGX_FENCE();
+    pf<0, 16>(B, fptr(packT, PT_K0 + 32), lane); mma<1, 0, 16>(dxa, dF[1], B); MGX_FENCE();
+    pf<1, 16>(B, fptr(packT, PT_K0 + 48), lane); mma<0, 0, 16>(dxa, dF[2], B); MGX_FENCE();
+    mma<1, 0, 16>(dxa, dF[3], B);
+    if (pvalid && h == 0) *(float2*)(dx + pc * 2) = make_float2(dxa[0], dxa[1]);
+}
+
+// ------------------------------------------------------------------------------------------
+// weight gradients
+// ------------------------------------------------------------------------------------------
+struct GJob {
+    int rowA, rowB;          // first activation / gradient row of sub-position term 0
+    int nsub;                // terms contracted besides the positions (sub-positions sharing the weight)
+    int strideA, strideB;    // row stride between terms
+    int bias;                // 1: also sum the gradient operand over positions
+    int nsplit;              // waves sharing the job (slabs)
+    int pad;
+    long ws_off;             // float offset of the job's slabs in the workspace
+};
+constexpr int NJOBS = 39;
+struct GJobs {
+    GJob j[NJOBS];
+};
+
+template <int TA, int TB>
+struct Frags {
+    f32x4 a[TA][4], b[TB][4];
+};
+
+template <int TA, int TB>
+__device__ __forceinline__ void load_frags(Frags<TA, TB>& f, const float* __restrict__ act,
+                                           const float* __restrict__ delta, const GJob& jb, long pt, int sub, int i,
+                                           int h) {
+    const float* pa = act + (pt * GB_ROWS + jb.rowA + sub * jb.strideA + i) * 32L + 16 * h;
+    const float* pb = delta + (pt * GB_ROWS + jb.rowB + sub * jb.strideB + i) * 32L + 16 * h;
+#pragma unroll
+    for (int t = 0; t < TA; ++t)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) f.a[t][q] = *(const f32x4*)(pa + t * 1024 + q * 4);
+#pragma unroll
+    for (int u = 0; u < TB; ++u)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) f.b[u][q] = *(const f32x4*)(pb + u * 1024 + q * 4);
+}
+
+template <int TA, int TB>
+__global__ __launch_bounds__(256, 1) void gblock_wgrad_kernel(const float* __restrict__ act,
+                                                              const float* __restrict__ delta, GJobs jobs, int job0,
+                                                              float* __restrict__ ws, long ntiles) {
+    const GJob jb = jobs.j[job0 + blockIdx.y];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int i = lane & 31, h = lane >> 5;
+    const long split = (long)blockIdx.x * 4 + wv, nw = (long)gridDim.x * 4;
+    f32x16 acc[TA][TB];
+    float bs[TB];
+#pragma unroll
+    for (int t = 0; t < TA; ++t)
+#pragma unroll
+        for (int u = 0; u < TB; ++u) zero(acc[t][u]);
+#pragma unroll
+    for (int u = 0; u < TB; ++u) bs[u] = 0.f;
+
+    long pt = split;
+    int sub = 0;
+    Frags<TA, TB> cur, nxt;
+    if (pt < ntiles) load_frags<TA, TB>(cur, act, delta, jb, pt, 0, i, h);
+    while (pt < ntiles) {
+        long ptn = pt;
+        int subn = sub + 1;
+        if (subn == jb.nsub) { subn = 0; ptn = pt + nw; }
+        const bool more = ptn < ntiles;
+        if (more) load_frags<TA, TB>(nxt, act, delta, jb, ptn, subn, i, h);
+#pragma unroll
+        for (int q = 0; q < 4; ++q)
+#pragma unroll
+            for (int e = 0; e < 4; ++e)
+#pragma unroll
+                for (int t = 0; t < TA; ++t)
+#pragma unroll
+                    for (int u = 0; u < TB; ++u) acc[t][u] = mfma32(cur.a[t][q][e], cur.b[u][q][e], acc[t][u]);
+        if (jb.bias) {
+#pragma unroll
+            for (int u = 0; u < TB; ++u)
+#pragma unroll
+                for (int q = 0; q < 4; ++q) bs[u] += (cur.b[u][q][0] + cur.b[u][q][1]) + (cur.b[u][q][2] + cur.b[u][q][3]);
+        }
+        MGX_FENCE();
+        if (more) cur = nxt;
+        pt = ptn;
+        sub = subn;
+    }
+    float* slab = ws + jb.ws_off + split * (TA * TB * 1024L + TB * 64L);
+#pragma unroll
+    for (int t = 0; t < TA; ++t)
+#pragma unroll
+        for (int u = 0; u < TB; ++u)
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) slab[((t * TB + u) * 16 + reg) * 64 + lane] = acc[t][u][reg];
+#pragma unroll
+    for (int u = 0; u < TB; ++u) slab[TA * TB * 1024 + u * 64 + lane] = bs[u];
+}
+
+// job numbering (see build_jobs): 0-3 W1, 4-9 D2_k, 10-11 W2, 12 W3, 13 W4, 14-19 D1_k,
+// 20-31 K2_k[b], 32-37 K1_k, 38 K0
+struct JobShape {
+    int ta, tb;
+};
+__host__ __device__ inline JobShape job_shape(int j) {
+    if (j < 10) return {2, 4};
+    if (j < 12) return {4, 2};
+    if (j < 13) return {2, 1};
+    if (j < 20) return {1, 1};
+    if (j < 32) return {1, 2};
+    if (j < 38) return {4, 1};
+    return {1, 4};
+}
+
+// sum over the job's slabs of accumulator element (tile, ci, co)
+__device__ __forceinline__ float slab_sum(const float* __restrict__ ws, const GJob& jb, int j, int tile, int ci, int co) {
+    const JobShape sh = job_shape(j);
+    const long stride = sh.ta * sh.tb * 1024L + sh.tb * 64L;
+    const int lane = co + 32 * ((ci >> 2) & 1), reg = (ci & 3) + 4 * (ci >> 3);
+    const float* p = ws + jb.ws_off + (tile * 16 + reg) * 64 + lane;
+    float s = 0.f;
+    for (int sp = 0; sp < jb.nsplit; ++sp) s += p[sp * stride];
+    return s;
+}
+
+__device__ __forceinline__ float bias_sum(const float* __restrict__ ws, const GJob& jb, int j, int u, int col) {
+    const JobShape sh = job_shape(j);
+    const long stride = sh.ta * sh.tb * 1024L + sh.tb * 64L;
+    const float* p = ws + jb.ws_off + sh.ta * sh.tb * 1024L + u * 64 + col;
+    float s = 0.f;
+    for (int sp = 0; sp < jb.nsplit; ++sp) s += p[sp * stride] + p[sp * stride + 32];
+    return s;
+}
+
+constexpr int BR_PARAMS = 4096 + 16 + 512 + 32 + 4096 + 64 + 8192 + 128;   // 17136
+constexpr int N_PARAMS = 1024 + 128 + 6 * BR_PARAMS + 32768 + 256 + 16384 + 64 + 512 + 8 + 16 + 2;   // 153978
+
+__global__ __launch_bounds__(256) void gblock_unpack_kernel(mgx_gblock_grads g, GJobs jobs,
+                                                            const float* __restrict__ ws) {
+    int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= N_PARAMS) return;
+    float* dst;
+    float v;
+    if (e < 1024) {                                   // K0 [tap][c][n]
+        const int c = (e >> 7) & 1, n = e & 127;
+        dst = g.k0 + e;
+        v = slab_sum(ws, jobs.j[38], 38, n >> 5, c, n & 31);
+    } else if ((e -= 1024) < 128) {                   // b0
+        dst = g.b0 + e;
+        v = bias_sum(ws, jobs.j[38], 38, e >> 5, e & 31);
+    } else if ((e -= 128) < 6 * BR_PARAMS) {
+        const int k = e / BR_PARAMS;
+        e -= k * BR_PARAMS;
+        if (e < 4096) {                               // K1 [a][co][ci]
+            const int aco = e >> 7, ci = e & 127;
+            dst = g.k1[k] + e;
+            v = slab_sum(ws, jobs.j[32 + k], 32 + k, ci >> 5, ci & 31, aco);
+        } else if ((e -= 4096) < 16) {                // b1
+            dst = g.b1[k] + e;
+            v = bias_sum(ws, jobs.j[32 + k], 32 + k, 0, e) + bias_sum(ws, jobs.j[32 + k], 32 + k, 0, 16 + e);
+        } else if ((e -= 16) < 512) {                 // D1 [in 16][out 32]
+            dst = g.d1[k] + e;
+            v = slab_sum(ws, jobs.j[14 + k], 14 + k, 0, e >> 5, e & 31);
+        } else if ((e -= 512) < 32) {                 // c1
+            dst = g.c1[k] + e;
+            v = bias_sum(ws, jobs.j[14 + k], 14 + k, 0, e);
+        } else if ((e -= 32) < 4096) {                // K2 [b][co][ci]
+            const int b = e >> 11, co = (e >> 5) & 63, ci = e & 31;
+            const int j = 20 + k * 2 + b;
+            dst = g.k2[k] + e;
+            v = slab_sum(ws, jobs.j[j], j, co >> 5, ci, co & 31);
+        } else if ((e -= 4096) < 64) {                // b2
+            const int j = 20 + k * 2;
+            dst = g.b2[k] + e;
+            v = bias_sum(ws, jobs.j[j], j, e >> 5, e & 31) + bias_sum(ws, jobs.j[j + 1], j + 1, e >> 5, e & 31);
+        } else if ((e -= 64) < 8192) {                // D2 [in 64][out 128]
+            const int in = e >> 7, out = e & 127;
+            dst = g.d2[k] + e;
+            v = slab_sum(ws, jobs.j[4 + k], 4 + k, (in >> 5) * 4 + (out >> 5), in & 31, out & 31);
+        } else {                                      // c2: the Add hands every branch the same gradient
+            e -= 8192;
+            dst = g.c2[k] + e;
+            v = bias_sum(ws, jobs.j[4], 4, e >> 5, e & 31);
+        }
+    } else if ((e -= 6 * BR_PARAMS) < 32768) {        // W1 [in 128][out 256]
+        const int in = e >> 8, out = e & 255;
+        const int j = (in >> 6) * 2 + (out >> 7);
+        dst = g.w1 + e;
+        v = slab_sum(ws, jobs.j[j], j, ((in & 63) >> 5) * 4 + ((out & 127) >> 5), in & 31, out & 31);
+    } else if ((e -= 32768) < 256) {                  // e1
+        const int j = e >> 7;
+        dst = g.e1 + e;
+        v = bias_sum(ws, jobs.j[j], j, (e & 127) >> 5, e & 31);
+    } else if ((e -= 256) < 16384) {                  // W2 [in 256][out 64]
+        const int in = e >> 6, out = e & 63;
+        const int j = 10 + (in >> 7);
+        dst = g.w2 + e;
+        v = slab_sum(ws, jobs.j[j], j, ((in & 127) >> 5) * 2 + (out >> 5), in & 31, out & 31);
+    } else if ((e -= 16384) < 64) {                   // e2
+        dst = g.e2 + e;
+        v = bias_sum(ws, jobs.j[10], 10, e >> 5, e & 31);
+    } else if ((e -= 64) < 512) {                     // W3 [in 64][out 8]
+        const int in = e >> 3, out = e & 7;
+        dst = g.w3 + e;
+        v = slab_sum(ws, jobs.j[12], 12, in >> 5, in & 31, out);
+    } else if ((e -= 512) < 8) {                      // e3
+        dst = g.e3 + e;
+        v = bias_sum(ws, jobs.j[12], 12, 0, e);
+    } else if ((e -= 8) < 16) {                       // W4 [in 8][out 2]
+        dst = g.w4 + e;
+        v = slab_sum(ws, jobs.j[13], 13, 0, e >> 1, e & 1);
+    } else {                                          // e4
+        e -= 16;
+        dst = g.e4 + e;
+        v = bias_sum(ws, jobs.j[13], 13, 0, e);
+    }
+    *dst += v;
+}
+
+// launches per accumulator shape: first job, number of jobs
+struct ShapeRun {
+    int ta, tb, job0, njobs;
+};
+const ShapeRun kRuns[7] = {{2, 4, 0, 10}, {4, 2, 10, 2}, {2, 1, 12, 1}, {1, 1, 13, 7}, {1, 2, 20, 12}, {4, 1, 32, 6},
+                           {1, 4, 38, 1}};
+
+int grid_x(long ntiles, int njobs) {
+    long x = (ntiles + 3) / 4;
+    const long cap = njobs >= 8 ? 48 : 64;
+    if (x > cap) x = cap;
+    return (int)(x < 1 ? 1 : x);
+}
+
+// Fill the job table for `ntiles` position tiles; returns the workspace size in floats.
+long build_jobs(GJobs& J, long ntiles) {
+    auto set = [&](int j, int rowA, int rowB, int nsub, int sA, int sB, int bias) {
+        J.j[j] = GJob{rowA, rowB, nsub, sA, sB, bias, 0, 0, 0};
+    };
+    for (int ab = 0; ab < 2; ++ab)
+        for (int bb = 0; bb < 2; ++bb) set(ab * 2 + bb, GB_S + 64 * ab, GB_T1 + 128 * bb, 4, 128, 256, ab == 0);
+    for (int k = 0; k < 6; ++k) set(4 + k, GB_BR + k * GB_BR_ROWS + GB_O3, GB_S, 4, 64, 128, k == 0);
+    for (int ab = 0; ab < 2; ++ab) set(10 + ab, GB_T1 + 128 * ab, GB_T2, 4, 256, 64, ab == 0);
+    set(12, GB_T2, GB_T3, 4, 64, 8, 1);
+    set(13, GB_T3, GB_X, 4, 8, 2, 1);
+    for (int k = 0; k < 6; ++k) {
+        const int br = GB_BR + k * GB_BR_ROWS;
+        set(14 + k, br + GB_O1, br + GB_O2, 2, 16, 32, 1);
+        for (int b = 0; b < 2; ++b) set(20 + k * 2 + b, br + GB_O2, br + GB_O3 + 64 * b, 2, 32, 128, 1);
+        set(32 + k, GB_F, br + GB_O1, 1, 0, 0, 1);
+    }
+    set(38, GB_X, GB_F, 1, 0, 0, 1);
+    long off = 0;
+    for (const ShapeRun& run : kRuns) {
+        const int nsplit = grid_x(ntiles, run.njobs) * 4;
+        for (int j = run.job0; j < run.job0 + run.njobs; ++j) {
+            J.j[j].nsplit = nsplit;
+            J.j[j].ws_off = off;
+            off += (long)nsplit * (run.ta * run.tb * 1024L + run.tb * 64L);
+        }
+    }
+    return off;
+}
+
+template <int TA, int TB>
+void launch_wgrad(const ShapeRun& run, const float* act, const float* delta, const GJobs& J, float* ws, long ntiles,
+                  hipStream_t st) {
+    dim3 grid(grid_x(ntiles, run.njobs), run.njobs);
+    hipLaunchKernelGGL((gblock_wgrad_kernel<TA, TB>), grid, dim3(256), 0, st, act, delta, J, run.job0, ws, ntiles);
+}
+
+bool all_set(const void* strukt, size_t bytes) {
+    const void* const* ptrs = (const void* const*)strukt;
+    for (size_t i = 0; i < bytes / sizeof(void*); ++i)
+        if (!ptrs[i]) return false;
+    return true;
+}
+
+}  // namespace
+
+extern "C" int64_t mgx_gblock_packt_floats(void) { return PACKT_FLOATS; }
+
+extern "C" int64_t mgx_gblock_wgrad_workspace(int64_t nimg, int hl, int wl) {
+    if (nimg <= 0 || hl <= 0 || wl <= 0) return 0;
+    const long ntiles = (((long)nimg * hl * wl + 127) / 128) * 4;
+    GJobs J;
+    return build_jobs(J, ntiles) * (int64_t)sizeof(float);
+}
+
+extern "C" int mgx_gblock_dgrad_f32(const mgx_gblock_weights* wp, float* packt, const float* dy, float* delta,
+                                    float* dx, int64_t nimg, int hl, int wl, void* stream) {
+    if (!wp || !packt || !dy || !delta || !dx || nimg <= 0 || hl <= 0 || wl <= 0) return MGX_ERR_ARG;
+    const mgx_gblock_weights w = *wp;
+    if (!all_set(&w, sizeof(w))) return MGX_ERR_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    hipLaunchKernelGGL(gblock_packT_kernel, dim3((PACKT_FLOATS + 255) / 256), dim3(256), 0, st, w, packt);
+    const long npix = (long)nimg * hl * wl;
+    const long blocks = (npix + 127) / 128;
+    if (blocks > 0x7fffffffL) return MGX_ERR_ARG;
+    hipLaunchKernelGGL(gblock_dgrad_kernel, dim3((unsigned)blocks), dim3(256), 0, st, packt, dy, delta, dx, npix, hl,
+                       wl);
+    return mgx_launch_status();
+}
+
+extern "C" int mgx_gblock_wgrad_f32(const float* act, const float* delta, const mgx_gblock_grads* gp, void* workspace,
+                                    int64_t workspace_bytes, int64_t nimg, int hl, int wl, void* stream) {
+    if (!act || !delta || !gp || !workspace || nimg <= 0 || hl <= 0 || wl <= 0) return MGX_ERR_ARG;
+    const mgx_gblock_grads g = *gp;
+    if (!all_set(&g, sizeof(g))) return MGX_ERR_ARG;
+    const long ntiles = (((long)nimg * hl * wl + 127) / 128) * 4;
+    GJobs J;
+    const long need = build_jobs(J, ntiles);
+    if (workspace_bytes < need * (int64_t)sizeof(float)) return MGX_ERR_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    float* ws = (float*)workspace;
+    launch_wgrad<2, 4>(kRuns[0], act, delta, J, ws, ntiles, st);
+    launch_wgrad<4, 2>(kRuns[1], act, delta, J, ws, ntiles, st);
+    launch_wgrad<2, 1>(kRuns[2], act, delta, J, ws, ntiles, st);
+    launch_wgrad<1, 1>(kRuns[3], act, delta, J, ws, ntiles, st);
+    launch_wgrad<1, 2>(kRuns[4], act, delta, J, ws, ntiles, st);
+    launch_wgrad<4, 1>(kRuns[5], act, delta, J, ws, ntiles, st);
+    launch_wgrad<1, 4>(kRuns[6], act, delta, J, ws, ntiles, st);
+    hipLaunchKernelGGL(gblock_unpack_kernel, dim3((N_PARAMS + 255) / 256), dim3(256), 0, st, g, J, ws);
+    return mgx_launch_status();
+}

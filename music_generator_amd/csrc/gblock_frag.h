@@ -1,0 +1,38 @@
+// Register-fragment helpers shared by the fused generator-block kernels (gblock.hip forward,
+// gblock_bwd.hip data-gradient): weight fragments are 64-float lane-ordered records streamed
+// through two 16-register buffers while the MFMAs of the previous group run.
+#pragma once
+#include "common.h"
+
+constexpr int FR = 64;   // floats per fragment (one per lane)
+
+// channel held by accumulator register s in lane half h (= contraction index of MFMA step s)
+__device__ __forceinline__ int chan(int s, int h) { return (s & 3) + 8 * (s >> 2) + 4 * h; }
+
+struct WBuf {
+    float v[2][16];
+};
+
+template <int P, int NS>
+__device__ __forceinline__ void pf(WBuf& B, const float* __restrict__ frag, int lane) {
+#pragma unroll
+    for (int s = 0; s < NS; ++s) B.v[P][s] = frag[s * FR + lane];
+}
+
+// acc += sum_{s < NS} B.v[P][s] (A operand: weights) x tile[S0 + s] (B operand: activations)
+template <int P, int S0, int NS>
+__device__ __forceinline__ void mma(f32x16& acc, const f32x16& tile, const WBuf& B) {
+#pragma unroll
+    for (int s = 0; s < NS; ++s) acc = mfma32(B.v[P][s], tile[S0 + s], acc);
+}
+
+#define MGX_FENCE() __builtin_amdgcn_sched_barrier(0)
+
+__device__ __forceinline__ const float* fptr(const float* pack, int frag) { return pack + (long)frag * FR; }
+
+// rows chan(s, h), s < NREG, of an accumulator tile -> 32-position rows of a tile-major side buffer
+template <int NREG>
+__device__ __forceinline__ void save_rows(float* __restrict__ buf, int row0, const f32x16& t, int r, int h) {
+#pragma unroll
+    for (int s = 0; s < NREG; ++s) buf[(row0 + chan(s, h)) * 32 + r] = t[s];
+}

@@ -141,11 +141,21 @@ class _Op:
 
 
 class FusedGroup:
-    """A sub-graph (input tensor -> output tensor through `nodes`) for which one fused kernel
-    exists.  Used only by forwards that keep no tape; `run(x)` returns the output tensor."""
+    """A sub-graph (input tensor -> output tensor through `nodes`) for which fused kernels exist.
+    `run(x)` returns the output tensor (forwards that keep no tape).  When `run_save` and
+    `backward` are set, taped forwards use the group too: `run_save(x)` returns (y, saved) and
+    `backward(saved, dy, need_weight_grads)` returns dx after adding the weight gradients of the
+    group's layers into their bound gradient views."""
 
     def __init__(self, input: KTensor, output: KTensor, nodes: List[Node], optional_nodes: List[Node], run):
         self.input, self.output, self.nodes, self.optional_nodes, self.run = input, output, nodes, optional_nodes, run
+        self.run_save = None
+        self.backward = None
+
+
+class Tape(list):
+    """Saved tensors of one taped forward, aligned with the plan that produced them."""
+    plan = None
 
 
 class _FusedOp:
@@ -159,7 +169,8 @@ class _FusedOp:
 class Model:
     """keras.Model(inputs, outputs) for single-input single-output graphs."""
 
-    use_fused_groups = True      # tape-free forwards may use fused sub-graph kernels
+    use_fused_groups = True      # forwards may use fused sub-graph kernels
+    use_fused_backward = True    # taped forwards too, where the group has a fused backward
 
     def __init__(self, inputs: KTensor, outputs: KTensor, name: Optional[str] = None):
         if isinstance(inputs, (list, tuple)) or isinstance(outputs, (list, tuple)):
@@ -325,13 +336,23 @@ class Model:
         """Run the plan.  Returns (y, tape); tape is None unless save=True."""
         x = self._to_device(x)
         vals: Dict[int, torch.Tensor] = {id(self.input): x}
-        tape = [] if save else None
-        plan = self._plan if (save or not Model.use_fused_groups) else self._plan_infer
+        tape = Tape() if save else None
+        fused = Model.use_fused_groups and self._plan_infer is not self._plan
+        if fused and save:
+            fused = Model.use_fused_backward and all(op.group.backward is not None for op in self._plan_infer
+                                                     if isinstance(op, _FusedOp))
+        plan = self._plan_infer if fused else self._plan
         last_use = self._last_use if plan is self._plan else self._last_use_infer
+        if save:
+            tape.plan = plan
         for i, op in enumerate(plan):
             xs = [vals[id(t)] for t in op.inputs]
             if isinstance(op, _FusedOp):
-                vals[id(op.output)] = op.group.run(xs[0])
+                if save:
+                    vals[id(op.output)], saved = op.group.run_save(xs[0])
+                    tape.append(saved)
+                else:
+                    vals[id(op.output)] = op.group.run(xs[0])
                 for t in op.inputs:
                     if last_use.get(id(t)) == i and t is not self.output:
                         vals.pop(id(t), None)
@@ -395,8 +416,9 @@ class Model:
         """Reverse sweep.  Weight gradients are ADDED into the variables' bound `.grad` views.
         Returns the gradient w.r.t. the model input (or None)."""
         grads: Dict[int, Tuple[torch.Tensor, bool]] = {id(self.output): (dy, False)}
-        for i in range(len(self._plan) - 1, -1, -1):
-            op = self._plan[i]
+        plan = getattr(tape, "plan", None) or self._plan
+        for i in range(len(plan) - 1, -1, -1):
+            op = plan[i]
             g = grads.pop(id(op.output), None)
             if g is None:
                 continue
@@ -411,7 +433,17 @@ class Model:
                 else:
                     pending.append(None)
                     existing.append(e[0] if e is not None else None)
-            res = op.node.layer.backward(tape[i], g[0], need, existing, need_weight_grads)
+            if isinstance(op, _FusedOp):
+                dx = op.group.backward(tape[i], g[0], need_weight_grads)
+                if not need[0]:
+                    res = [None]
+                elif existing[0] is not None:
+                    ops.add_inplace(existing[0], dx)
+                    res = [(existing[0], True)]
+                else:
+                    res = [(dx, True)]
+            else:
+                res = op.node.layer.backward(tape[i], g[0], need, existing, need_weight_grads)
             tape[i] = None
             for t, r, pend in zip(op.inputs, res, pending):
                 if r is None:

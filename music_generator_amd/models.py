@@ -242,27 +242,68 @@ def _register_fused_block(block_end, upsampling, for_sum_layer):
     tail_layers = [n.layer for n in tail[::-1]]   # Dense(256), Dense(64), Dense(8), Dense(2)
     state = {}
 
-    def run(x):
+    layer_fields = [(feat_node.layer, "k0", "b0", None)]
+    for k, ch in enumerate(branch_nodes):
+        for name_k, name_b, node in (("k1", "b1", ch[0]), ("d1", "c1", ch[1]), ("k2", "b2", ch[2]), ("d2", "c2", ch[3])):
+            layer_fields.append((node.layer, name_k, name_b, k))
+    for i, layer in enumerate(tail_layers):
+        layer_fields.append((layer, "w%d" % (i + 1), "e%d" % (i + 1), None))
+
+    def pointers(of):
+        w = _cabi.GBlockWeights()
+        for layer, name_k, name_b, k in layer_fields:
+            pk, pb = of(layer.kernel).data_ptr(), of(layer.bias).data_ptr()
+            if k is None:
+                setattr(w, name_k, pk)
+                setattr(w, name_b, pb)
+            else:
+                getattr(w, name_k)[k] = pk
+                getattr(w, name_b)[k] = pb
+        return w
+
+    def weights():
         if "w" not in state:
-            w = _cabi.GBlockWeights()
-            f = feat_node.layer
-            w.k0, w.b0 = f.kernel.value().data_ptr(), f.bias.value().data_ptr()
-            for k, ch in enumerate(branch_nodes):
-                for name_k, name_b, node in (("k1", "b1", ch[0]), ("d1", "c1", ch[1]), ("k2", "b2", ch[2]),
-                                             ("d2", "c2", ch[3])):
-                    getattr(w, name_k)[k] = node.layer.kernel.value().data_ptr()
-                    getattr(w, name_b)[k] = node.layer.bias.value().data_ptr()
-            for i, layer in enumerate(tail_layers):
-                setattr(w, "w%d" % (i + 1), layer.kernel.value().data_ptr())
-                setattr(w, "e%d" % (i + 1), layer.bias.value().data_ptr())
-            state["w"] = w
+            state["w"] = pointers(lambda v: v.value())
             state["pack"] = K.empty((ops.gblock_pack_floats(),))
+        return state["w"]
+
+    def run(x):
+        w = weights()
         n, hl, wl, _ = x.shape
         y = K.empty((n, 2 * hl, 2 * wl, 2))
-        ops.gblock_fwd(state["w"], state["pack"], x, y, n, hl, wl)
+        ops.gblock_fwd(w, state["pack"], x, y, n, hl, wl)
         return y
 
-    for_sum_layer.fused_group = FusedGroup(block_end, for_sum_layer, nodes, [upsampling.node], run)
+    def run_save(x):
+        """Forward that also keeps the block's intermediate tensors (one tile-major buffer)."""
+        w = weights()
+        n, hl, wl, _ = x.shape
+        y = K.empty((n, 2 * hl, 2 * wl, 2))
+        act = K.empty((ops.gblock_side_floats(n, hl, wl),))
+        ops.gblock_fwd(w, state["pack"], x, y, n, hl, wl, act=act)
+        return y, (act, (n, hl, wl))
+
+    def backward(saved, dy, need_weight_grads):
+        act, (n, hl, wl) = saved
+        w = weights()
+        if "packt" not in state:
+            state["packt"] = K.empty((ops.gblock_packt_floats(),))
+        delta = K.empty((ops.gblock_side_floats(n, hl, wl),))
+        dx = K.empty((n, hl, wl, 2))
+        ops.gblock_dgrad(w, state["packt"], dy, delta, dx, n, hl, wl)
+        if need_weight_grads:
+            for layer, _, _, _ in layer_fields:
+                if layer.kernel.grad is None or layer.bias.grad is None:
+                    raise RuntimeError("gradient buffers of %s are not bound" % layer.name)
+
+            def grad_of(v):
+                return v.grad
+            ops.gblock_wgrad(act, delta, pointers(grad_of), n, hl, wl)
+        return dx
+
+    group = FusedGroup(block_end, for_sum_layer, nodes, [upsampling.node], run)
+    group.run_save, group.backward = run_save, backward
+    for_sum_layer.fused_group = group
 
 
 def add_generator_block(old_model):
