@@ -99,11 +99,12 @@ def load():
     global _lib
     if _lib is not None:
         return _lib
-    if not os.path.exists(LIB_PATH):
+    path = os.environ.get("MGX_LIBRARY", LIB_PATH)      # override: diagnostic builds of the same ABI
+    if not os.path.exists(path):
         raise MgxError(
             "libmgx.so not found at %s: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
-            "(there is no CPU or PyTorch fallback for this path)" % LIB_PATH)
-    lib = C.CDLL(LIB_PATH)
+            "(there is no CPU or PyTorch fallback for this path)" % path)
+    lib = C.CDLL(path)
     for name, (res, args) in PROTOTYPES.items():
         fn = getattr(lib, name)     # AttributeError if the symbol is missing
         fn.restype = res

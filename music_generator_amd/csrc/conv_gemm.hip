@@ -155,30 +155,53 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(mgx_conv_desc d, const f
             const long rbase = row0 + pt * 32;
             RowPos p0;
             if (scatter) p0 = decode_row(rbase, d.hout, d.wout);
+            // offsets first, then loads (accumulate), arithmetic and stores in separate sweeps so
+            // that the memory operations of the 16 elements are in flight together
+            long off[16];
+            bool okr[16];
 #pragma unroll
             for (int reg = 0; reg < 16; ++reg) {
                 const int rl = acc_row(reg, lane);
                 const long row = rbase + rl;
-                if (row >= R) continue;
-                long off;
+                okr[reg] = row < R;
                 if (scatter) {
                     long im = p0.img;
                     int hh = p0.ho, ww = p0.wo + rl;
                     while (ww >= d.wout) { ww -= d.wout; ++hh; }
                     while (hh >= d.hout) { hh -= d.hout; ++im; }
-                    off = ((im * d.hout + hh) * d.dkh * out_w + (long)ww * d.dkw) * d.cout + npart;
+                    off[reg] = ((im * d.hout + hh) * d.dkh * out_w + (long)ww * d.dkw) * d.cout + npart;
                 } else {
-                    off = row * d.ngemm + npart;
+                    off[reg] = row * d.ngemm + npart;
                 }
-                float v = acc[pt][nt][reg] + bv;
-                if (d.act_alpha > 0.f) {
+                if (!okr[reg]) off[reg] = 0;
+            }
+            float v[16], der[16];
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) v[reg] = acc[pt][nt][reg] + bv;
+            const bool act = d.act_alpha > 0.f;
+            if (act) {
+#pragma unroll
+                for (int reg = 0; reg < 16; ++reg) {
                     float t, s2;
-                    tanh_sech2(v, t, s2);
-                    if (dact) dact[off] = s2 + inv_alpha;
-                    v = t + v / d.act_alpha;
+                    tanh_sech2(v[reg], t, s2);
+                    der[reg] = s2 + inv_alpha;
+                    v[reg] = t + v[reg] / d.act_alpha;
                 }
-                if (d.accumulate) v += y[off];
-                y[off] = v;
+            }
+            if (d.accumulate) {
+                float old[16];
+#pragma unroll
+                for (int reg = 0; reg < 16; ++reg) old[reg] = okr[reg] ? y[off[reg]] : 0.f;
+#pragma unroll
+                for (int reg = 0; reg < 16; ++reg) v[reg] += old[reg];
+            }
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg)
+                if (okr[reg]) y[off[reg]] = v[reg];
+            if (act && dact) {
+#pragma unroll
+                for (int reg = 0; reg < 16; ++reg)
+                    if (okr[reg]) dact[off[reg]] = der[reg];
             }
         }
     }

@@ -174,6 +174,9 @@ bool mgx_tconv_applicable(const mgx_conv_desc& d) {
     if (d.cin != 32 && d.ngemm != 32) return false;
     if (d.cin > 128 || d.ngemm > 128) return false;
     if (d.hin % TH) return false;
+    // the tile kernels address one window of rows / one output row through 32-bit buffer offsets
+    if ((long)(TH + 2) * d.win * (d.cin > d.ngemm ? d.cin : d.ngemm) * 4 >= (1L << 31)) return false;
+    if ((long)d.nimg * (d.hin / TH) * ((d.win + TW - 1) / TW) >= (1L << 31)) return false;
     if (d.nbias != 0 && d.nbias != d.ngemm) return false;
     // weight strides the kernels hard-code: [k][n] rows of 32 (forward) or [n][k] rows of 32 (data-gradient)
     const bool kn = d.wsk == 32 && d.wsn == 1 && d.ngemm == 32;

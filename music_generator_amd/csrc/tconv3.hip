@@ -73,30 +73,46 @@ __global__ __launch_bounds__(512, 2) void tconv3_kernel(mgx_conv_desc d, const f
     };
 
     // ---- input tile: thread t moves float4 #(t + 512 i), i < SITER ----
+    // Addressing goes through a buffer resource per tile that spans the IH image rows of the tile
+    // window (< 4 GiB): a 32-bit byte offset per load, and positions outside the image get an
+    // out-of-range offset, for which the hardware returns zeros - no clamping, no selects, no
+    // 64-bit address arithmetic per element.
     const int c4 = tid & 7;
     auto tile_of = [&](long t, long& img, int& h0, int& w0) {
-        const int per_img = tiles_h * tiles_w;
-        img = t / per_img;
-        const int rem = (int)(t - img * per_img);
-        const int th = rem / tiles_w;
-        h0 = th * TH;
-        w0 = (rem - th * tiles_w) * TW;
+        const unsigned per_img = (unsigned)(tiles_h * tiles_w);
+        const unsigned tu = (unsigned)t;                    // ntiles < 2^31 (checked by the launcher)
+        const unsigned im = tu / per_img;
+        const unsigned rem = tu - im * per_img;
+        const unsigned th = rem / (unsigned)tiles_w;
+        img = im;
+        h0 = (int)th * TH;
+        w0 = (int)(rem - th * tiles_w) * TW;
     };
+    const unsigned band_bytes = (unsigned)IH * W * d.cin * 4u;
+    int rel[SITER], tyx[SITER];          // byte offset of the element inside the tile window; (ty << 16) | tx
+#pragma unroll
+    for (int i = 0; i < SITER; ++i) {
+        const int px = (tid >> 3) + 64 * i;
+        const int ty = px / IW, tx = px - ty * IW;
+        rel[i] = ((ty * W + tx) * d.cin + c4 * 4) * 4;
+        tyx[i] = px < NPIX ? ((ty << 16) | tx) : (0x7000 << 16);      // never inside an image
+    }
     f32x4 sv[SITER], sm[SITER];
-    bool sok[SITER];
     auto stage_load = [&](long t, int kc) {
         long img; int h0, w0;
         tile_of(t, img, h0, w0);
+        const int hb = h0 - d.pt, wb = w0 - d.pl;
+        const int base = (wb * d.cin + kc * 32) * 4;
+        const long band = ((img * H + hb) * (long)W) * d.cin;      // first row of the window (may lie above the image)
+        const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)(x + band), 0, band_bytes, 0x00020000);
+        __amdgpu_buffer_rsrc_t rm = rx;
+        if (MUL) rm = __builtin_amdgcn_make_buffer_rsrc((void*)(xmul + band), 0, band_bytes, 0x00020000);
 #pragma unroll
         for (int i = 0; i < SITER; ++i) {
-            const int px = (tid >> 3) + 64 * i;
-            const int ty = px / IW, tx = px - ty * IW;
-            const int hi = h0 - d.pt + ty, wi = w0 - d.pl + tx;
-            sok[i] = px < NPIX && hi >= 0 && hi < H && wi >= 0 && wi < W;
-            const int hc = min(max(hi, 0), H - 1), wc = min(max(wi, 0), W - 1);
-            const long off = ((img * H + hc) * W + wc) * (long)d.cin + kc * 32 + c4 * 4;
-            sv[i] = *(const f32x4*)(x + off);
-            if (MUL) sm[i] = *(const f32x4*)(xmul + off);
+            const unsigned hi = (unsigned)((tyx[i] >> 16) + hb), wi = (unsigned)((tyx[i] & 0xffff) + wb);
+            const unsigned off = (hi < (unsigned)H && wi < (unsigned)W) ? (unsigned)(base + rel[i]) : 0xfffffff0u;
+            sv[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, off, 0, 0));
+            if (MUL) sm[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rm, off, 0, 0));
         }
     };
     auto stage_write = [&](float* buf) {
@@ -105,8 +121,7 @@ __global__ __launch_bounds__(512, 2) void tconv3_kernel(mgx_conv_desc d, const f
             const int px = (tid >> 3) + 64 * i;
             f32x4 v = sv[i];
             if (MUL) v *= sm[i];
-            if (!sok[i]) v = (f32x4){0.f, 0.f, 0.f, 0.f};
-            if (px < NPIX) *(f32x4*)(buf + px * PSTR + c4 * 4) = v;
+            if (64 * (i + 1) <= NPIX || px < NPIX) *(f32x4*)(buf + px * PSTR + c4 * 4) = v;
         }
     };
 
@@ -124,7 +139,72 @@ __global__ __launch_bounds__(512, 2) void tconv3_kernel(mgx_conv_desc d, const f
     f32x16 acc;
 #pragma unroll
     for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+
+    // ---- epilogue of row wv of tile t_, output channels [32 nc, 32 nc + 32) ----
+    // loads (accumulate), arithmetic and stores run in separate sweeps: 16 independent memory
+    // operations in flight instead of one round trip per element
+    // Stores go through a buffer resource that spans exactly the output row of this wave: columns
+    // past the row end are dropped by the hardware range check, the per-register part of the
+    // offset is a scalar, so a store costs no vector ALU work.
+    const int wvs = __builtin_amdgcn_readfirstlane(wv);
+    const unsigned row_bytes = (unsigned)W * d.ngemm * 4u;
+    auto epilogue = [&](const f32x16& a, long t_, int oc_) {
+        const int n = (nchunks > 1 ? oc_ : 0) * 32 + r;
+        const float bv = d.nbias > 0 ? bias[n] : 0.f;
+        long img; int h0, w0;
+        tile_of(t_, img, h0, w0);
+        const long rowoff = ((img * H + h0 + wvs) * (long)W) * d.ngemm;
+        const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc((void*)(y + rowoff), 0, row_bytes, 0x00020000);
+        const unsigned voff = (unsigned)(((w0 + 4 * h) * d.ngemm + n) * 4);
+        const int rstep = d.ngemm * 4;                  // bytes per output position
+        const bool act = d.act_alpha > 0.f;
+        float v[16], der[16];
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg) v[reg] = a[reg] + bv;
+        if (act) {
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) {
+                float tt, s2;
+                tanh_sech2(v[reg], tt, s2);
+                der[reg] = s2 + inv_alpha;
+                v[reg] = tt + v[reg] * inv_alpha;
+            }
+        }
+        if (d.accumulate) {
+            float old[16];
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg)
+                old[reg] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                                                         ry, voff, ((reg & 3) + 8 * (reg >> 2)) * rstep, 0));
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) v[reg] += old[reg];
+        }
+#pragma unroll
+        for (int reg = 0; reg < 16; ++reg)
+            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v[reg]), ry, voff,
+                                                  ((reg & 3) + 8 * (reg >> 2)) * rstep, 0);
+        if (act && dact) {
+            const __amdgpu_buffer_rsrc_t rd =
+                __builtin_amdgcn_make_buffer_rsrc((void*)(dact + rowoff), 0, row_bytes, 0x00020000);
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg)
+                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, der[reg]), rd, voff,
+                                                      ((reg & 3) + 8 * (reg >> 2)) * rstep, 0);
+        }
+    };
+    // The two waves of a SIMD (w and w + 4) are kept half a phase apart: the upper four waves carry
+    // their finished accumulator over the barrier and run its epilogue at the start of the next
+    // step, while the lower four are already issuing MFMAs; at the end of the step the roles swap.
+    const bool late = wvs >= 4;
+    f32x16 pend;
+    long pend_t = 0;
+    int pend_oc = 0;
+    bool pend_valid = false;
     while (t < ntiles) {
+        if (pend_valid) {
+            epilogue(pend, pend_t, pend_oc);
+            pend_valid = false;
+        }
         // the step after this one: next output/input chunk of the same tile, or the next tile
         int ocn = oc + 1;
         long tn = t;
@@ -135,46 +215,40 @@ __global__ __launch_bounds__(512, 2) void tconv3_kernel(mgx_conv_desc d, const f
         if (need_x) stage_load(tn, kchunks > 1 ? ocn : 0);     // in flight during the MFMA phase
         if (need_w) w_load(ocn);
         const float* xb = xt + cur * (NPIX * PSTR);
+        // 4*TAPS quads of (4 input channels x 32 outputs); the LDS reads of quad q+2 are issued
+        // before the MFMAs of quad q, so their latency is covered by 8 MFMAs of this wave
+        {
+            constexpr int NQ = 4 * TAPS;
+            const float* abase = xb + (wv * IW + r) * PSTR + 16 * h;
+            const float* wbase = wl + (4 * h) * 128 + r * 4;
+            f32x4 aq[3], wq[3];
+            auto rd = [&](int q, int slot) {
+                const int tap = q >> 2, j = q & 3;
+                const int ta = tap / KW, tb = tap - ta * KW;
+                aq[slot] = *(const f32x4*)(abase + (ta * IW + tb) * PSTR + 4 * j);
+                wq[slot] = *(const f32x4*)(wbase + tap * 1024 + j * 128);
+            };
+            rd(0, 0);
+            rd(1, 1);
 #pragma unroll
-        for (int ta = 0; ta < KH; ++ta)
+            for (int q = 0; q < NQ; ++q) {
+                if (q + 2 < NQ) rd(q + 2, (q + 2) % 3);
 #pragma unroll
-            for (int tb = 0; tb < KW; ++tb) {
-                const float* asrc = xb + ((wv + ta) * IW + (r + tb)) * PSTR + 16 * h;
-                const float* wsrc = wl + ((ta * KW + tb) * 8 + 4 * h) * 128 + r * 4;
-#pragma unroll
-                for (int j = 0; j < 4; ++j) {
-                    const f32x4 av = *(const f32x4*)(asrc + 4 * j);
-                    const f32x4 wv4 = *(const f32x4*)(wsrc + j * 128);
-#pragma unroll
-                    for (int s = 0; s < 4; ++s) acc = mfma32(av[s], wv4[s], acc);
-                }
+                for (int s = 0; s < 4; ++s) acc = mfma32(aq[q % 3][s], wq[q % 3][s], acc);
+                __builtin_amdgcn_sched_barrier(0);
             }
+        }
         if (kchunks == 1 || oc == S - 1) {
-            // ---- epilogue: row wv of the tile, output channels [32 nc, 32 nc + 32) ----
-            const int n = (nchunks > 1 ? oc : 0) * 32 + r;
-            const float bv = d.nbias > 0 ? bias[n] : 0.f;
-            long img; int h0, w0;
-            tile_of(t, img, h0, w0);
-            const long rowoff = ((img * H + h0 + wv) * (long)W + w0) * d.ngemm + n;
-            float* __restrict__ yrow = y + rowoff;
-            float* __restrict__ drow = dact ? dact + rowoff : nullptr;
-#pragma unroll
-            for (int reg = 0; reg < 16; ++reg) {
-                const int cl = acc_row(reg, lane);
-                if (w0 + cl < W) {
-                    const int off = cl * d.ngemm;
-                    float v = acc[reg] + bv;
-                    if (d.act_alpha > 0.f) {
-                        float tt, s2;
-                        tanh_sech2(v, tt, s2);
-                        if (drow) drow[off] = s2 + inv_alpha;
-                        v = tt + v * inv_alpha;
-                    }
-                    if (d.accumulate) v += yrow[off];
-                    yrow[off] = v;
-                }
-                acc[reg] = 0.f;
+            if (late) {
+                pend = acc;
+                pend_t = t;
+                pend_oc = oc;
+                pend_valid = true;
+            } else {
+                epilogue(acc, t, oc);
             }
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) acc[reg] = 0.f;
         }
         if (S > 1) __syncthreads();        // every wave is done with the weight slice
         if (need_x) stage_write(xt + (cur ^ 1) * (NPIX * PSTR));
@@ -184,6 +258,7 @@ __global__ __launch_bounds__(512, 2) void tconv3_kernel(mgx_conv_desc d, const f
         t = tn;
         oc = ocn;
     }
+    if (pend_valid) epilogue(pend, pend_t, pend_oc);
 }
 
 template <int KH, int KW>
