@@ -228,7 +228,75 @@ int launch_pn(const mgx_conv_desc& d, const float* x, const float* xmul, const f
     return mgx_launch_status();
 }
 
+// ------------------------------------------------------------------------------------------
+// 1x1 convolution of a 2-channel input (the discriminator's from-audio layers, models.py:236 and
+// 262): two multiply-adds per output, so it runs on the vector ALUs at the HBM write rate.  A
+// thread owns 4 consecutive output channels (weights and bias in registers) and walks positions;
+// a wave writes two whole 128-channel rows (1 KiB) per store instruction.
+// ------------------------------------------------------------------------------------------
+template <bool ACT, bool DACT>
+__global__ __launch_bounds__(256) void pointwise2_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                         const float* __restrict__ bias, float* __restrict__ y,
+                                                         float* __restrict__ dact, long npos, int n, float alpha,
+                                                         int pos_per_block) {
+    const int q = n >> 2;                         // threads per position
+    const int c = (threadIdx.x % q) * 4, pl = threadIdx.x / q, pstep = 256 / q;
+    const f32x4 w0 = *(const f32x4*)(w + c), w1 = *(const f32x4*)(w + n + c), b = *(const f32x4*)(bias + c);
+    const float inv_alpha = ACT ? 1.0f / alpha : 0.f;
+    const long p0 = (long)blockIdx.x * pos_per_block;
+    const long p1 = p0 + pos_per_block < npos ? p0 + pos_per_block : npos;
+#pragma unroll 2
+    for (long p = p0 + pl; p < p1; p += pstep) {
+        const float2 xv = *(const float2*)(x + p * 2);
+        f32x4 v = w0 * xv.x + (w1 * xv.y + b);
+        if (ACT) {
+            f32x4 der;
+#pragma unroll
+            for (int j = 0; j < 4; ++j) {
+                float t, s2;
+                tanh_sech2(v[j], t, s2);
+                der[j] = s2 + inv_alpha;
+                v[j] = t + v[j] / alpha;
+            }
+            if (DACT) __builtin_nontemporal_store(der, (f32x4*)(dact + p * n + c));
+        }
+        __builtin_nontemporal_store(v, (f32x4*)(y + p * n + c));
+    }
+}
+
+bool pointwise2_applicable(const mgx_conv_desc& d, const float* xmul) {
+    return d.cin == 2 && d.kh == 1 && d.kw == 1 && d.sh == 1 && d.sw == 1 && d.dkh == 1 && d.dkw == 1 &&
+           d.pt == 0 && d.pl == 0 && d.hout == d.hin && d.wout == d.win && d.ngemm == d.cout && d.ngemm % 4 == 0 &&
+           256 % (d.ngemm / 4) == 0 && d.ngemm <= 1024 && d.wsn == 1 && d.wsk == d.ngemm && d.nbias == d.ngemm &&
+           !d.accumulate && !xmul;
+}
+
+int launch_pointwise2(const mgx_conv_desc& d, const float* x, const float* w, const float* bias, float* y,
+                      float* dact, hipStream_t st) {
+    const long npos = (long)d.nimg * d.hin * d.win;
+    const int pstep = 256 / (d.ngemm / 4);
+    // about 8 workgroups per CU, whole multiples of the positions one pass covers
+    long ppb = (npos + 2047) / 2048;
+    ppb = ((ppb + pstep - 1) / pstep) * pstep;
+    if (ppb < pstep) ppb = pstep;
+    const long blocks = (npos + ppb - 1) / ppb;
+    dim3 grid((unsigned)blocks), block(256);
+    const bool act = d.act_alpha > 0.f;
+    if (act && dact)
+        hipLaunchKernelGGL((pointwise2_kernel<true, true>), grid, block, 0, st, x, w, bias, y, dact, npos, d.ngemm,
+                           d.act_alpha, (int)ppb);
+    else if (act)
+        hipLaunchKernelGGL((pointwise2_kernel<true, false>), grid, block, 0, st, x, w, bias, y, dact, npos, d.ngemm,
+                           d.act_alpha, (int)ppb);
+    else
+        hipLaunchKernelGGL((pointwise2_kernel<false, false>), grid, block, 0, st, x, w, bias, y, dact, npos, d.ngemm,
+                           1.0f, (int)ppb);
+    return mgx_launch_status();
+}
+
 }  // namespace
+
+bool mgx_pointwise2_applicable(const mgx_conv_desc& d) { return pointwise2_applicable(d, nullptr); }
 
 extern "C" int mgx_conv_gemm_f32(const mgx_conv_desc* dp, const float* x, const float* xmul, const float* w,
                                  const float* bias, float* y, float* dact, void* stream) {
@@ -243,6 +311,7 @@ extern "C" int mgx_conv_gemm_f32(const mgx_conv_desc* dp, const float* x, const 
     // out-of-range positions are treated as zero padding, never dereferenced.
     hipStream_t st = (hipStream_t)stream;
     if (mgx_tconv_applicable(d)) return mgx_tconv_launch(d, x, xmul, w, bias, y, dact, st);
+    if (pointwise2_applicable(d, xmul)) return launch_pointwise2(d, x, w, bias, y, dact, st);
     const int ntiles = (d.ngemm + 31) / 32;
     if (ntiles == 1) return launch_pn<4, 1>(d, x, xmul, w, bias, y, dact, st);
     if (ntiles == 2) return launch_pn<2, 2>(d, x, xmul, w, bias, y, dact, st);

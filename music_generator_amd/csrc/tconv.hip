@@ -197,9 +197,13 @@ int mgx_tconv_launch(const mgx_conv_desc& d, const float* x, const float* xmul, 
 // weight gradient: same applicability on the FORWARD descriptor, output channels must be 32
 bool mgx_twgrad_applicable(const mgx_conv_desc& d) { return mgx_tconv_applicable(d) && d.ngemm == 32 && d.flip == 0; }
 
+bool mgx_pointwise2_applicable(const mgx_conv_desc& d);   // conv_gemm.hip
+
 extern "C" int mgx_conv_route(const mgx_conv_desc* d, int wgrad) {
     if (!d) return 0;
-    return (wgrad ? mgx_twgrad_applicable(*d) : mgx_tconv_applicable(*d)) ? 1 : 0;
+    if (wgrad) return mgx_twgrad_applicable(*d) ? 1 : 0;
+    if (mgx_tconv_applicable(*d)) return 1;
+    return mgx_pointwise2_applicable(*d) ? 2 : 0;
 }
 
 long mgx_twgrad_splits(const mgx_conv_desc& d) {

@@ -56,7 +56,10 @@ PROFILER: Optional[LaunchProfiler] = None
 
 
 def _gemm_key(d: ConvDesc, mul: bool = False) -> str:
-    if _lib().mgx_conv_route(C.byref(d), 0):
+    route = _lib().mgx_conv_route(C.byref(d), 0)
+    if route == 2 and not mul:
+        return "pointwise2_kernel"
+    if route == 1:
         return "tconv3_kernel<%d,%d,%s,%s>" % (d.kh, d.kw, "true" if d.wsk == 1 else "false",
                                                "true" if mul else "false")
     nt = (d.ngemm + 31) // 32
