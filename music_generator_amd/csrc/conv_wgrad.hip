@@ -255,10 +255,86 @@ void launch_wgrad(const mgx_conv_desc& d, const WgradPlan& p, const float* x, co
                        p.tap_groups, p.k_groups, p.ktot, p.ntot, p.rows_per_split, p.tiles_total);
 }
 
+// ------------------------------------------------------------------------------------------
+// Weight / bias gradient of a 1x1 convolution with a 2-channel input (from-audio layers): three
+// sums per output channel over all positions, on the vector ALUs at the HBM read rate.  A thread
+// owns 4 channels and a strided share of the block's positions; the block's partial sums go to the
+// workspace and a second kernel adds the blocks in order (bitwise reproducible).
+// ------------------------------------------------------------------------------------------
+template <bool MUL>
+__global__ __launch_bounds__(256) void pointwise2_wgrad_kernel(const float* __restrict__ x,
+                                                               const float* __restrict__ dy,
+                                                               const float* __restrict__ dymul,
+                                                               float* __restrict__ partial, long npos, int n,
+                                                               int pos_per_block) {
+    extern __shared__ __attribute__((aligned(16))) float red[];      // [3][pstep][n]
+    const int q = n >> 2;
+    const int c = (threadIdx.x % q) * 4, pl = threadIdx.x / q, pstep = 256 / q;
+    f32x4 a0 = {0.f, 0.f, 0.f, 0.f}, a1 = a0, ab = a0;
+    const long p0 = (long)blockIdx.x * pos_per_block;
+    const long p1 = p0 + pos_per_block < npos ? p0 + pos_per_block : npos;
+#pragma unroll 4
+    for (long p = p0 + pl; p < p1; p += pstep) {
+        f32x4 g = __builtin_nontemporal_load((const f32x4*)(dy + p * n + c));
+        if (MUL) g *= __builtin_nontemporal_load((const f32x4*)(dymul + p * n + c));
+        const float2 xv = *(const float2*)(x + p * 2);
+        a0 += g * xv.x;
+        a1 += g * xv.y;
+        ab += g;
+    }
+    *(f32x4*)(red + (0 * pstep + pl) * n + c) = a0;
+    *(f32x4*)(red + (1 * pstep + pl) * n + c) = a1;
+    *(f32x4*)(red + (2 * pstep + pl) * n + c) = ab;
+    __syncthreads();
+    for (int e = threadIdx.x; e < 3 * n; e += 256) {
+        const int k = e / n, col = e - k * n;
+        float s = 0.f;
+        for (int j = 0; j < pstep; ++j) s += red[(k * pstep + j) * n + col];
+        partial[(long)blockIdx.x * 3 * n + e] = s;
+    }
+}
+
+__global__ __launch_bounds__(256) void pointwise2_wgrad_reduce_kernel(const float* __restrict__ partial,
+                                                                      float* __restrict__ dw,
+                                                                      float* __restrict__ dbias, int nblocks, int n) {
+    const int e = blockIdx.x * 256 + threadIdx.x;
+    if (e >= 3 * n) return;
+    float s = 0.f;
+    for (int b = 0; b < nblocks; ++b) s += partial[(long)b * 3 * n + e];
+    if (e < 2 * n) dw[e] += s;
+    else if (dbias) dbias[e - 2 * n] += s;
+}
+
+bool pointwise2_wgrad_applicable(const mgx_conv_desc& d) {
+    return d.cin == 2 && d.kh == 1 && d.kw == 1 && d.sh == 1 && d.sw == 1 && d.dkh == 1 && d.dkw == 1 &&
+           d.pt == 0 && d.pl == 0 && d.hout == d.hin && d.wout == d.win && d.ngemm == d.cout && d.ngemm % 4 == 0 &&
+           256 % (d.ngemm / 4) == 0 && d.ngemm <= 1024 && d.wsn == 1 && d.wsk == d.ngemm &&
+           (d.nbias == d.ngemm || d.nbias == 0);
+}
+
+struct Pw2Plan {
+    long npos, ppb;
+    int blocks, pstep;
+};
+
+Pw2Plan pointwise2_wgrad_plan(const mgx_conv_desc& d) {
+    Pw2Plan p;
+    p.npos = (long)d.nimg * d.hin * d.win;
+    p.pstep = 256 / (d.ngemm / 4);
+    long ppb = (p.npos + 1023) / 1024;
+    ppb = ((ppb + p.pstep - 1) / p.pstep) * p.pstep;
+    if (ppb < p.pstep) ppb = p.pstep;
+    p.ppb = ppb;
+    p.blocks = (int)((p.npos + ppb - 1) / ppb);
+    return p;
+}
+
 }  // namespace
 
 extern "C" int64_t mgx_conv_wgrad_workspace(const mgx_conv_desc* dp) {
     if (!dp) return -1;
+    if (pointwise2_wgrad_applicable(*dp))
+        return (int64_t)pointwise2_wgrad_plan(*dp).blocks * 3 * dp->ngemm * (int64_t)sizeof(float);
     const WgradPlan p = make_plan(*dp);
     return (p.partial_floats + p.bias_floats) * (int64_t)sizeof(float);
 }
@@ -270,6 +346,22 @@ extern "C" int mgx_conv_wgrad_f32(const mgx_conv_desc* dp, const float* x, const
     if (d.nimg <= 0 || d.cin <= 0 || d.hout <= 0 || d.wout <= 0 || d.kh <= 0 || d.kw <= 0) return MGX_ERR_ARG;
     if (d.ngemm != d.dkh * d.dkw * d.cout) return MGX_ERR_ARG;
     if (dbias && d.nbias <= 0) return MGX_ERR_ARG;
+    if (pointwise2_wgrad_applicable(d)) {
+        const Pw2Plan pp = pointwise2_wgrad_plan(d);
+        if ((int64_t)pp.blocks * 3 * d.ngemm * (int64_t)sizeof(float) > workspace_bytes) return MGX_ERR_WORKSPACE;
+        hipStream_t s2 = (hipStream_t)stream;
+        float* part = (float*)workspace;
+        const int lds = 3 * pp.pstep * d.ngemm * (int)sizeof(float);
+        if (dymul)
+            hipLaunchKernelGGL((pointwise2_wgrad_kernel<true>), dim3(pp.blocks), dim3(256), lds, s2, x, dy, dymul, part,
+                               pp.npos, d.ngemm, (int)pp.ppb);
+        else
+            hipLaunchKernelGGL((pointwise2_wgrad_kernel<false>), dim3(pp.blocks), dim3(256), lds, s2, x, dy, dymul,
+                               part, pp.npos, d.ngemm, (int)pp.ppb);
+        hipLaunchKernelGGL(pointwise2_wgrad_reduce_kernel, dim3((3 * d.ngemm + 255) / 256), dim3(256), 0, s2, part, dw,
+                           dbias, pp.blocks, d.ngemm);
+        return mgx_launch_status();
+    }
     const WgradPlan p = make_plan(d);
     if ((p.partial_floats + p.bias_floats) * (int64_t)sizeof(float) > workspace_bytes) return MGX_ERR_WORKSPACE;
     hipStream_t st = (hipStream_t)stream;

@@ -201,7 +201,7 @@ bool mgx_pointwise2_applicable(const mgx_conv_desc& d);   // conv_gemm.hip
 
 extern "C" int mgx_conv_route(const mgx_conv_desc* d, int wgrad) {
     if (!d) return 0;
-    if (wgrad) return mgx_twgrad_applicable(*d) ? 1 : 0;
+    if (wgrad) return mgx_twgrad_applicable(*d) ? 1 : (mgx_pointwise2_applicable(*d) ? 2 : 0);
     if (mgx_tconv_applicable(*d)) return 1;
     return mgx_pointwise2_applicable(*d) ? 2 : 0;
 }

@@ -68,7 +68,10 @@ def _gemm_key(d: ConvDesc, mul: bool = False) -> str:
 
 
 def _wgrad_key(d: ConvDesc) -> str:
-    if _lib().mgx_conv_route(C.byref(d), 1):
+    route = _lib().mgx_conv_route(C.byref(d), 1)
+    if route == 2:
+        return "pointwise2_wgrad_kernel"
+    if route == 1:
         return "twgrad_kernel<%d,%d>" % (d.kh, d.kw)
     taps, kt, nt = d.kh * d.kw, (d.cin + 31) // 32, (d.ngemm + 31) // 32
     if taps % 9 == 0:
