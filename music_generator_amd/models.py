@@ -440,6 +440,7 @@ class WGAN:
         self.dist = None                      # parallel.DataParallel when sharded over GPUs
         self.last_losses = None
         self.micro_batch = None               # samples per micro-batch (multiple of 4); None = whole batch
+        self.generator_chunk = None           # samples per generator backward chunk (see train_step)
         self._mb_cache: Dict = {}
         self._ones_cache: Dict = {}
         self._latents: List = []
@@ -591,12 +592,24 @@ class WGAN:
         sums = K.zeros((2,))
         for idx in batches:
             zb, rb = self._take(z, idx), self._take(real, idx)
-            gen, tape_g = G.forward(zb, save=True)
+            nb = zb.shape[0]
+            chunk = self.generator_chunk if (self.generator_chunk and self.generator_chunk < nb) else None
+            gen, tape_g = G.forward(zb, save=chunk is None)
             gen_logits, tape_d = D.forward(gen, save=True)
             del gen
-            dgen = D.backward(tape_d, self._ones(rb.shape[0]), need_input_grad=True, need_weight_grads=False)
-            G.backward(tape_g, dgen, need_input_grad=False)
-            del tape_d, tape_g, dgen
+            dgen = D.backward(tape_d, self._ones(nb), need_input_grad=True, need_weight_grads=False)
+            del tape_d
+            if chunk is None:
+                G.backward(tape_g, dgen, need_input_grad=False)
+            else:
+                # The generator has no cross-sample op (its LayerNormalization is per sample), so
+                # its taped forward + backward can run on fewer samples than the discriminator's
+                # MinibatchStdDev groups allow: one extra generator forward buys a tape of `chunk`
+                # samples instead of a micro-batch.
+                for s0 in range(0, nb, chunk):
+                    _, tape_g = G.forward(zb[s0:s0 + chunk], save=True)
+                    G.backward(tape_g, dgen[s0:s0 + chunk], need_input_grad=False)
+            del tape_g, dgen
             real_logits = D(rb)
             ops.logit_sums(gen_logits.view(-1), real_logits.view(-1), sums, accumulate=True)
         out_g, cf, _ = self._finish_sums(sums, 1, n, True)

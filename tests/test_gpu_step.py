@@ -230,9 +230,11 @@ def test_micro_batching_reproduces_whole_batch_step():
     n_blocks, stage, batch = 2, 1, 16
     real, z4 = R.synthetic_inputs(stage, batch, seed=5)
     results = []
-    for mb in (None, 4, 8):
+    for mb in (None, 4, 8, (8, 2)):
         d, g, comp, W = build(n_blocks)
         gan = comp[stage][1]
+        if isinstance(mb, tuple):            # (micro-batch, generator backward chunk)
+            mb, gan.generator_chunk = mb
         gan.micro_batch = mb
         gan.set_train_steps(11)
         gan.actual_step = 3

@@ -14,6 +14,8 @@ import music_generator_amd as M
 STEP_GFLOP = [13.6, 59.9, 245.0, 985.0, 3947.0, 15794.0, 63182.0]
 # (batch, micro_batch) per stage: large batches at low resolution, memory-bounded micro-batches above
 PLAN = {0: (256, None), 1: (256, None), 2: (128, None), 3: (64, None), 4: (32, 16), 5: (16, 4), 6: (4, 4)}
+# generator backward chunk (samples): only where a micro-batch of generator activations does not fit
+GEN_CHUNK = {6: 1}
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--stages", default="0,1,2,3,4,5")
@@ -30,6 +32,7 @@ for stage in [int(s) for s in args.stages.split(",")]:
     fade = args.fade and stage > 0
     gan = M.define_composite(d, g, (1, 100, 2))[stage][1 if fade else 0]
     gan.micro_batch = mb
+    gan.generator_chunk = GEN_CHUNK.get(stage)
     gan.set_train_steps(100)
     h, w = 4 << stage, 750 << stage
     real = torch.rand((batch, h, w, 2), device="cuda") * 2 - 1
@@ -40,10 +43,13 @@ for stage in [int(s) for s in args.stages.split(",")]:
         m = gan.train_step(real)
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / args.steps
-    print(json.dumps({"stage": stage, "hw": [h, w], "batch": batch, "micro_batch": mb, "fade_in": fade,
+    print(json.dumps({"stage": stage, "hw": [h, w], "batch": batch, "micro_batch": mb, "generator_chunk": GEN_CHUNK.get(stage),
+                      "fade_in": fade,
                       "ms_per_step": round(dt * 1e3, 2), "samples_per_s": round(batch / dt, 3),
                       "algorithmic_tflops": round(STEP_GFLOP[stage] * batch / dt / 1e3, 2),
                       "frac_f32_mfma_peak": round(STEP_GFLOP[stage] * batch / dt / 1e3 / 157.3, 4),
                       "peak_hbm_gib": round(torch.cuda.max_memory_allocated() / 2**30, 1),
+                      "peak_reserved_gib": round(torch.cuda.max_memory_reserved() / 2**30, 1),
+                      "alloc_retries": torch.cuda.memory_stats().get("num_alloc_retries", 0),
                       "delta_1": float(m["delta_1"])}), flush=True)
     del gan, d, g, real
