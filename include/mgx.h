@@ -104,22 +104,28 @@ typedef struct {
 } mgx_gblock_weights;
 
 int64_t mgx_gblock_pack_floats(void);
-/* `act` = NULL: nothing but y is written.  Otherwise `act` is a buffer of
- * mgx_gblock_side_floats(nimg, hl, wl) floats that receives every intermediate tensor the weight
- * gradients need (the tape of tf.GradientTape, models.py:141-144), in the tile-major layout the
- * backward entry points read. */
+/* All three entry points work on a range of low-resolution positions [pos0, pos0 + npos) of the
+ * flattened (nimg, hl, wl) grid (pos0 a multiple of 128; npos <= 0: through the end), so a caller can
+ * bound the size of the side buffers: tile t of a side buffer is positions pos0 + 32t ...; a side
+ * buffer for n positions holds mgx_gblock_side_floats_n(n) floats.  A sequence of calls over
+ * ranges must start with pos0 = 0: that call refills `pack` / `packt` from the weights.
+ *
+ * Forward: `act` = NULL writes nothing but y.  Otherwise `act` receives every intermediate tensor
+ * the weight gradients need (the tape of tf.GradientTape, models.py:141-144) in the tile-major
+ * layout the backward entry points read; y may then be NULL (re-computation of the tape). */
+int64_t mgx_gblock_side_floats_n(int64_t npos);
 int64_t mgx_gblock_side_floats(int64_t nimg, int hl, int wl);
 int mgx_gblock_fwd_f32(const mgx_gblock_weights* w, float* pack, const float* x, float* y, float* act,
-                       int64_t nimg, int hl, int wl, void* stream);
+                       int64_t nimg, int hl, int wl, int64_t pos0, int64_t npos, void* stream);
 
 /* Backward of the same block (the generator part of tape.gradient, models.py:144-146).
- * mgx_gblock_dgrad_f32: dy (nimg, 2*hl, 2*wl, 2) -> dx (nimg, hl, wl, 2), and every intermediate
- * gradient into `delta` (mgx_gblock_side_floats floats); `packt` is scratch of
- * mgx_gblock_packt_floats() floats refilled from the weights.
- * mgx_gblock_wgrad_f32: ADDS the weight and bias gradients of all 58 tensors, computed from `act`
- * (saved by the forward) and `delta`, into the Keras-layout gradient tensors of `g` (same field
- * order as mgx_gblock_weights); `workspace` holds mgx_gblock_wgrad_workspace() bytes of per-split
- * partial sums that are added in fixed order (bitwise reproducible). */
+ * mgx_gblock_dgrad_f32: dy (nimg, 2*hl, 2*wl, 2) -> dx (nimg, hl, wl, 2) for the positions of the
+ * range, and every intermediate gradient into `delta` (side buffer of the range); `packt` is scratch
+ * of mgx_gblock_packt_floats() floats.
+ * mgx_gblock_wgrad_f32: ADDS the weight and bias gradients of all 58 tensors, computed from the side
+ * buffers `act` and `delta` of the same npos positions, into the Keras-layout gradient tensors of
+ * `g` (same field order as mgx_gblock_weights); `workspace` holds mgx_gblock_wgrad_workspace_n(npos)
+ * bytes of per-split partial sums that are added in fixed order (bitwise reproducible). */
 typedef struct {
     float *k0, *b0;
     float *k1[6], *b1[6];
@@ -130,11 +136,12 @@ typedef struct {
 } mgx_gblock_grads;
 
 int64_t mgx_gblock_packt_floats(void);
+int64_t mgx_gblock_wgrad_workspace_n(int64_t npos);
 int64_t mgx_gblock_wgrad_workspace(int64_t nimg, int hl, int wl);
 int mgx_gblock_dgrad_f32(const mgx_gblock_weights* w, float* packt, const float* dy, float* delta, float* dx,
-                         int64_t nimg, int hl, int wl, void* stream);
+                         int64_t nimg, int hl, int wl, int64_t pos0, int64_t npos, void* stream);
 int mgx_gblock_wgrad_f32(const float* act, const float* delta, const mgx_gblock_grads* g, void* workspace,
-                         int64_t workspace_bytes, int64_t nimg, int hl, int wl, void* stream);
+                         int64_t workspace_bytes, int64_t npos, void* stream);
 
 /* ------------------------------------------------------------------------------------------
  * Non-contraction layers (HBM-bound, coalesced, wavefront reductions)

@@ -60,12 +60,14 @@ PROTOTYPES = {
     "mgx_conv_wgrad_f32": (_I, [_DESC, _P, _P, _P, _P, _P, _P, _I64, _P]),
     "mgx_conv_route": (_I, [_DESC, _I]),
     "mgx_gblock_pack_floats": (_I64, []),
+    "mgx_gblock_side_floats_n": (_I64, [_I64]),
     "mgx_gblock_side_floats": (_I64, [_I64, _I, _I]),
-    "mgx_gblock_fwd_f32": (_I, [C.POINTER(GBlockWeights), _P, _P, _P, _P, _I64, _I, _I, _P]),
+    "mgx_gblock_fwd_f32": (_I, [C.POINTER(GBlockWeights), _P, _P, _P, _P, _I64, _I, _I, _I64, _I64, _P]),
     "mgx_gblock_packt_floats": (_I64, []),
+    "mgx_gblock_wgrad_workspace_n": (_I64, [_I64]),
     "mgx_gblock_wgrad_workspace": (_I64, [_I64, _I, _I]),
-    "mgx_gblock_dgrad_f32": (_I, [C.POINTER(GBlockWeights), _P, _P, _P, _P, _I64, _I, _I, _P]),
-    "mgx_gblock_wgrad_f32": (_I, [_P, _P, C.POINTER(GBlockWeights), _P, _I64, _I64, _I, _I, _P]),
+    "mgx_gblock_dgrad_f32": (_I, [C.POINTER(GBlockWeights), _P, _P, _P, _P, _I64, _I, _I, _I64, _I64, _P]),
+    "mgx_gblock_wgrad_f32": (_I, [_P, _P, C.POINTER(GBlockWeights), _P, _I64, _I64, _P]),
     "mgx_upsample2x_fwd": (_I, [_P, _P, _I64, _I, _I, _I, _P]),
     "mgx_upsample2x_bwd": (_I, [_P, _P, _I64, _I, _I, _I, _I, _P]),
     "mgx_avgpool2x_fwd": (_I, [_P, _P, _I64, _I, _I, _I, _P]),

@@ -16,6 +16,7 @@ _name_counts: Dict[str, int] = {}
 def clear_session():
     """Reset the auto-naming counters (keras.backend.clear_session analogue)."""
     _name_counts.clear()
+    _side.clear()
 
 
 def unique_name(cls_name: str) -> str:
@@ -117,6 +118,24 @@ def workspace(nbytes: int) -> torch.Tensor:
         _workspace.pop(key, None)
         cur = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=dev)
         _workspace[key] = cur
+    return cur
+
+
+_side: Dict[int, list] = {}
+
+
+def side_buffers(nfloats: int):
+    """Two persistent float32 scratch tensors of at least `nfloats` each (grow-only, per device):
+    the bounded side buffers of a re-computing fused backward.  Kept out of the caching allocator
+    so that their memory is not carved up between two uses."""
+    dev = device()
+    key = dev.index or 0
+    cur = _side.get(key)
+    if cur is None or cur[0].numel() < nfloats:
+        _side.pop(key, None)
+        cur = None
+        cur = [torch.empty((int(nfloats),), dtype=torch.float32, device=dev) for _ in range(2)]
+        _side[key] = cur
     return cur
 
 

@@ -244,7 +244,7 @@ __device__ __forceinline__ void half_block(const float* __restrict__ pack, float
         if (SAVE) save_rows<4>(act, GB_T3 + ab * 8, T3, r, h);
         MGX_FENCE();
         // rows 0,1 (the two output channels) live in registers 0,1 of lane half 0
-        if (pvalid && h == 0) *(float2*)(yrow + b * 2) = make_float2(O[0], O[1]);
+        if (pvalid && h == 0 && yrow) *(float2*)(yrow + b * 2) = make_float2(O[0], O[1]);
     };
     tail(std::integral_constant<int, P1>{}, std::integral_constant<int, 0>{});
     tail(std::integral_constant<int, P0>{}, std::integral_constant<int, 1>{});
@@ -253,10 +253,11 @@ __device__ __forceinline__ void half_block(const float* __restrict__ pack, float
 template <bool SAVE>
 __global__ __launch_bounds__(256, 1) void gblock_fwd_kernel(const float* __restrict__ pack,
                                                             const float* __restrict__ x, float* __restrict__ y,
-                                                            float* __restrict__ act, long npix, int hl, int wl) {
+                                                            float* __restrict__ act, long pos0, long npix, int hl,
+                                                            int wl, int store_y) {
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int r = lane & 31, h = lane >> 5;
-    const long p = ((long)blockIdx.x * 4 + wv) * 32 + r;
+    const long p = pos0 + ((long)blockIdx.x * 4 + wv) * 32 + r;    // side-buffer tiles are counted from pos0
     const bool pvalid = p < npix;
     const long pc = pvalid ? p : 0;
     // B operand of the featured conv: lane (position r, half h) supplies channel h of its position
@@ -265,8 +266,8 @@ __global__ __launch_bounds__(256, 1) void gblock_fwd_kernel(const float* __restr
     float* atile = SAVE ? act + ((long)blockIdx.x * 4 + wv) * (GB_ROWS * 32L) : nullptr;
     const long row = pc / wl;                 // n*hl + i
     const int j = (int)(pc - row * wl);
-    float* yrow0 = y + ((row * 2) * (2L * wl) + 2L * j) * 2;      // output row 2i,   column 2j
-    float* yrow1 = yrow0 + (2L * wl) * 2;                         // output row 2i+1
+    float* yrow0 = store_y ? y + ((row * 2) * (2L * wl) + 2L * j) * 2 : nullptr;      // output row 2i, column 2j
+    float* yrow1 = store_y ? yrow0 + (2L * wl) * 2 : nullptr;                         // output row 2i+1
     WBuf B;
     pf<0, 16>(B, fptr(pack, OFF_F), lane);
     half_block<0, 0, false, SAVE>(pack, x0, lane, h, pvalid, yrow0, B, fptr(pack, OFF_F), atile);
@@ -277,29 +278,35 @@ __global__ __launch_bounds__(256, 1) void gblock_fwd_kernel(const float* __restr
 
 extern "C" int64_t mgx_gblock_pack_floats(void) { return PACK_FLOATS; }
 
+extern "C" int64_t mgx_gblock_side_floats_n(int64_t npos) {
+    return npos <= 0 ? 0 : ((npos + 127) / 128) * 4 * (GB_ROWS * 32L);
+}
+
 extern "C" int64_t mgx_gblock_side_floats(int64_t nimg, int hl, int wl) {
     if (nimg <= 0 || hl <= 0 || wl <= 0) return 0;
-    const long npix = (long)nimg * hl * wl;
-    return ((npix + 127) / 128) * 4 * (GB_ROWS * 32L);
+    return mgx_gblock_side_floats_n((long)nimg * hl * wl);
 }
 
 extern "C" int mgx_gblock_fwd_f32(const mgx_gblock_weights* wp, float* pack, const float* x, float* y, float* act,
-                                  int64_t nimg, int hl, int wl, void* stream) {
-    if (!wp || !pack || !x || !y || nimg <= 0 || hl <= 0 || wl <= 0) return MGX_ERR_ARG;
+                                  int64_t nimg, int hl, int wl, int64_t pos0, int64_t npos, void* stream) {
+    if (!wp || !pack || !x || (!y && !act) || nimg <= 0 || hl <= 0 || wl <= 0) return MGX_ERR_ARG;
+    const long npix = (long)nimg * hl * wl;
+    if (pos0 < 0 || pos0 >= npix || (pos0 & 127)) return MGX_ERR_ARG;
+    const long end = (npos <= 0 || pos0 + npos > npix) ? npix : pos0 + npos;
     const mgx_gblock_weights w = *wp;
     const void* const* ptrs = (const void* const*)&w;
     for (size_t i = 0; i < sizeof(w) / sizeof(void*); ++i)
         if (!ptrs[i]) return MGX_ERR_ARG;
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(gblock_pack_kernel, dim3((PACK_FLOATS + 255) / 256), dim3(256), 0, st, w, pack);
-    const long npix = (long)nimg * hl * wl;
-    const long blocks = (npix + 127) / 128;
+    if (pos0 == 0)      // the packed fragments of a call sequence over ranges are filled by its first call
+        hipLaunchKernelGGL(gblock_pack_kernel, dim3((PACK_FLOATS + 255) / 256), dim3(256), 0, st, w, pack);
+    const long blocks = (end - pos0 + 127) / 128;
     if (blocks > 0x7fffffffL) return MGX_ERR_ARG;
     if (act)
-        hipLaunchKernelGGL(gblock_fwd_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, st, pack, x, y, act, npix, hl,
-                           wl);
+        hipLaunchKernelGGL(gblock_fwd_kernel<true>, dim3((unsigned)blocks), dim3(256), 0, st, pack, x, y, act,
+                           (long)pos0, end, hl, wl, y ? 1 : 0);
     else
-        hipLaunchKernelGGL(gblock_fwd_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, st, pack, x, y, act, npix,
-                           hl, wl);
+        hipLaunchKernelGGL(gblock_fwd_kernel<false>, dim3((unsigned)blocks), dim3(256), 0, st, pack, x, y, act,
+                           (long)pos0, end, hl, wl, 1);
     return mgx_launch_status();
 }

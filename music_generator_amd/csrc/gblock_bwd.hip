@@ -98,11 +98,11 @@ __device__ __forceinline__ void zero(f32x16& t) {
 __global__ __launch_bounds__(256, 1) void gblock_dgrad_kernel(const float* __restrict__ packT,
                                                               const float* __restrict__ dy,
                                                               float* __restrict__ delta, float* __restrict__ dx,
-                                                              long npix, int hl, int wl) {
+                                                              long pos0, long npix, int hl, int wl) {
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int r = lane & 31, h = lane >> 5;
-    const long tile = (long)blockIdx.x * 4 + wv;
-    const long p = tile * 32 + r;
+    const long tile = (long)blockIdx.x * 4 + wv;     // tile of the side buffer, counted from pos0
+    const long p = pos0 + tile * 32 + r;
     const bool pvalid = p < npix;
     const long pc = pvalid ? p : 0;
     const long row = pc / wl;                 // n*hl + i
@@ -498,34 +498,42 @@ bool all_set(const void* strukt, size_t bytes) {
 
 extern "C" int64_t mgx_gblock_packt_floats(void) { return PACKT_FLOATS; }
 
+extern "C" int64_t mgx_gblock_wgrad_workspace_n(int64_t npos) {
+    if (npos <= 0) return 0;
+    GJobs J;
+    return build_jobs(J, ((npos + 127) / 128) * 4) * (int64_t)sizeof(float);
+}
+
 extern "C" int64_t mgx_gblock_wgrad_workspace(int64_t nimg, int hl, int wl) {
     if (nimg <= 0 || hl <= 0 || wl <= 0) return 0;
-    const long ntiles = (((long)nimg * hl * wl + 127) / 128) * 4;
-    GJobs J;
-    return build_jobs(J, ntiles) * (int64_t)sizeof(float);
+    return mgx_gblock_wgrad_workspace_n((long)nimg * hl * wl);
 }
 
 extern "C" int mgx_gblock_dgrad_f32(const mgx_gblock_weights* wp, float* packt, const float* dy, float* delta,
-                                    float* dx, int64_t nimg, int hl, int wl, void* stream) {
+                                    float* dx, int64_t nimg, int hl, int wl, int64_t pos0, int64_t npos,
+                                    void* stream) {
     if (!wp || !packt || !dy || !delta || !dx || nimg <= 0 || hl <= 0 || wl <= 0) return MGX_ERR_ARG;
+    const long npix = (long)nimg * hl * wl;
+    if (pos0 < 0 || pos0 >= npix || (pos0 & 127)) return MGX_ERR_ARG;
+    const long end = (npos <= 0 || pos0 + npos > npix) ? npix : pos0 + npos;
     const mgx_gblock_weights w = *wp;
     if (!all_set(&w, sizeof(w))) return MGX_ERR_ARG;
     hipStream_t st = (hipStream_t)stream;
-    hipLaunchKernelGGL(gblock_packT_kernel, dim3((PACKT_FLOATS + 255) / 256), dim3(256), 0, st, w, packt);
-    const long npix = (long)nimg * hl * wl;
-    const long blocks = (npix + 127) / 128;
+    if (pos0 == 0)      // the packed fragments of a call sequence over ranges are filled by its first call
+        hipLaunchKernelGGL(gblock_packT_kernel, dim3((PACKT_FLOATS + 255) / 256), dim3(256), 0, st, w, packt);
+    const long blocks = (end - pos0 + 127) / 128;
     if (blocks > 0x7fffffffL) return MGX_ERR_ARG;
-    hipLaunchKernelGGL(gblock_dgrad_kernel, dim3((unsigned)blocks), dim3(256), 0, st, packt, dy, delta, dx, npix, hl,
-                       wl);
+    hipLaunchKernelGGL(gblock_dgrad_kernel, dim3((unsigned)blocks), dim3(256), 0, st, packt, dy, delta, dx, (long)pos0,
+                       end, hl, wl);
     return mgx_launch_status();
 }
 
 extern "C" int mgx_gblock_wgrad_f32(const float* act, const float* delta, const mgx_gblock_grads* gp, void* workspace,
-                                    int64_t workspace_bytes, int64_t nimg, int hl, int wl, void* stream) {
-    if (!act || !delta || !gp || !workspace || nimg <= 0 || hl <= 0 || wl <= 0) return MGX_ERR_ARG;
+                                    int64_t workspace_bytes, int64_t npos, void* stream) {
+    if (!act || !delta || !gp || !workspace || npos <= 0) return MGX_ERR_ARG;
     const mgx_gblock_grads g = *gp;
     if (!all_set(&g, sizeof(g))) return MGX_ERR_ARG;
-    const long ntiles = (((long)nimg * hl * wl + 127) / 128) * 4;
+    const long ntiles = ((npos + 127) / 128) * 4;
     GJobs J;
     const long need = build_jobs(J, ntiles);
     if (workspace_bytes < need * (int64_t)sizeof(float)) return MGX_ERR_WORKSPACE;

@@ -147,6 +147,10 @@ class FusedGroup:
     `backward(saved, dy, need_weight_grads)` returns dx after adding the weight gradients of the
     group's layers into their bound gradient views."""
 
+    # Upper bound in bytes for the block-sized scratch a group may hold from a taped forward to its
+    # backward (None: no bound).  Groups that would exceed it keep only their input and re-compute.
+    side_budget_bytes = None
+
     def __init__(self, input: KTensor, output: KTensor, nodes: List[Node], optional_nodes: List[Node], run):
         self.input, self.output, self.nodes, self.optional_nodes, self.run = input, output, nodes, optional_nodes, run
         self.run_save = None

@@ -275,30 +275,53 @@ def _register_fused_block(block_end, upsampling, for_sum_layer):
         return y
 
     def run_save(x):
-        """Forward that also keeps the block's intermediate tensors (one tile-major buffer)."""
+        """Taped forward.  With enough memory the block's intermediate tensors are kept (one
+        tile-major buffer); above FusedGroup.side_budget_bytes only the 2-channel input is kept and
+        the backward re-computes them range by range."""
         w = weights()
         n, hl, wl, _ = x.shape
         y = K.empty((n, 2 * hl, 2 * wl, 2))
-        act = K.empty((ops.gblock_side_floats(n, hl, wl),))
+        side = ops.gblock_side_floats(n * hl * wl)
+        budget = FusedGroup.side_budget_bytes
+        if budget is not None and 4 * side > budget:
+            ops.gblock_fwd(w, state["pack"], x, y, n, hl, wl)
+            return y, (None, x, (n, hl, wl))
+        act = K.empty((side,))
         ops.gblock_fwd(w, state["pack"], x, y, n, hl, wl, act=act)
-        return y, (act, (n, hl, wl))
+        return y, (act, None, (n, hl, wl))
 
     def backward(saved, dy, need_weight_grads):
-        act, (n, hl, wl) = saved
+        act, x, (n, hl, wl) = saved
         w = weights()
         if "packt" not in state:
             state["packt"] = K.empty((ops.gblock_packt_floats(),))
-        delta = K.empty((ops.gblock_side_floats(n, hl, wl),))
-        dx = K.empty((n, hl, wl, 2))
-        ops.gblock_dgrad(w, state["packt"], dy, delta, dx, n, hl, wl)
+        grads = None
         if need_weight_grads:
             for layer, _, _, _ in layer_fields:
                 if layer.kernel.grad is None or layer.bias.grad is None:
                     raise RuntimeError("gradient buffers of %s are not bound" % layer.name)
-
-            def grad_of(v):
-                return v.grad
-            ops.gblock_wgrad(act, delta, pointers(grad_of), n, hl, wl)
+            grads = pointers(lambda v: v.grad)
+        dx = K.empty((n, hl, wl, 2))
+        total = n * hl * wl
+        if act is not None:
+            delta = K.empty((ops.gblock_side_floats(total),))
+            ops.gblock_dgrad(w, state["packt"], dy, delta, dx, n, hl, wl)
+            if grads is not None:
+                ops.gblock_wgrad(act, delta, grads, total)
+            return dx
+        # re-computation: ranges of positions sized so that both side buffers fit the budget
+        per_pos = 4 * ops.gblock_side_floats(128) // 128
+        step = max(128, (FusedGroup.side_budget_bytes // (2 * per_pos)) // 128 * 128)
+        step = min(step, (total + 127) // 128 * 128)
+        floats = ops.gblock_side_floats(step)
+        bufs = K.side_buffers(floats)
+        for pos0 in range(0, total, step):
+            cnt = min(step, total - pos0)
+            if grads is not None:
+                ops.gblock_fwd(w, state["pack"], x, None, n, hl, wl, act=bufs[0], pos0=pos0, npos=cnt)
+            ops.gblock_dgrad(w, state["packt"], dy, bufs[1], dx, n, hl, wl, pos0=pos0, npos=cnt)
+            if grads is not None:
+                ops.gblock_wgrad(bufs[0], bufs[1], grads, cnt)
         return dx
 
     group = FusedGroup(block_end, for_sum_layer, nodes, [upsampling.node], run)

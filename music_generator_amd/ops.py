@@ -158,28 +158,13 @@ def gblock_pack_floats() -> int:
     return int(_lib().mgx_gblock_pack_floats())
 
 
-def gblock_side_floats(nimg, hl, wl) -> int:
-    return int(_lib().mgx_gblock_side_floats(nimg, hl, wl))
+def gblock_side_floats(npos) -> int:
+    """Floats of a side buffer (activations or gradients) of a fused grow block for npos positions."""
+    return int(_lib().mgx_gblock_side_floats_n(npos))
 
 
 def gblock_packt_floats() -> int:
     return int(_lib().mgx_gblock_packt_floats())
-
-
-def gblock_fwd(weights, pack, x, y, nimg, hl, wl, act=None):
-    """weights: _cabi.GBlockWeights; x (nimg,hl,wl,2) -> y (nimg,2hl,2wl,2); `act` (optional) receives
-    the intermediate tensors of the block for the backward entry points."""
-    if x.numel() != nimg * hl * wl * 2 or y.numel() != 4 * x.numel() or pack.numel() < gblock_pack_floats():
-        raise MgxError("gblock_fwd: size mismatch")
-    if act is not None and act.numel() < gblock_side_floats(nimg, hl, wl):
-        raise MgxError("gblock_fwd: activation buffer too small")
-    e0 = PROFILER.start() if PROFILER is not None else None
-    check(_lib().mgx_gblock_fwd_f32(C.byref(weights), _p(pack), _p(x), _p(y), _p(act), nimg, hl, wl,
-                                    K.stream_ptr()), "mgx_gblock_fwd_f32")
-    if e0 is not None:
-        PROFILER.stop("gblock_fwd_kernel<%s>" % ("true" if act is not None else "false"),
-                      GBLOCK_FLOP_PER_POSITION * nimg * hl * wl, e0,
-                      4.0 * (x.numel() + y.numel() + (act.numel() if act is not None else 0)))
 
 
 # 2 * multiply-adds of one grow block per low-resolution position (4 output positions)
@@ -187,34 +172,64 @@ GBLOCK_FLOP_PER_POSITION = 2.0 * (4 * 2 * 128 + 6 * (2 * 16 * 128 + 2 * 16 * 32 
                                   + 4 * (128 * 256 + 256 * 64 + 64 * 8 + 8 * 2))
 
 
-def gblock_dgrad(weights, packt, dy, delta, dx, nimg, hl, wl):
-    """dy (nimg,2hl,2wl,2) -> dx (nimg,hl,wl,2); `delta` receives the intermediate gradients."""
+def _gblock_range(nimg, hl, wl, pos0, npos):
+    total = nimg * hl * wl
+    if pos0 < 0 or pos0 >= total or pos0 % 128:
+        raise MgxError("gblock: the first position of a range must be a multiple of 128 inside the grid")
+    return min(npos, total - pos0) if npos and npos > 0 else total - pos0
+
+
+def gblock_fwd(weights, pack, x, y, nimg, hl, wl, act=None, pos0=0, npos=0):
+    """weights: _cabi.GBlockWeights; x (nimg,hl,wl,2) -> y (nimg,2hl,2wl,2) for the low-resolution
+    positions [pos0, pos0+npos) (default: all).  `act` (optional) receives the intermediate tensors
+    of the range for the backward entry points; y may then be None."""
+    n = _gblock_range(nimg, hl, wl, pos0, npos)
+    if x.numel() != nimg * hl * wl * 2 or pack.numel() < gblock_pack_floats():
+        raise MgxError("gblock_fwd: size mismatch")
+    if y is None and act is None:
+        raise MgxError("gblock_fwd: nothing to write")
+    if y is not None and y.numel() != 4 * x.numel():
+        raise MgxError("gblock_fwd: output size mismatch")
+    if act is not None and act.numel() < gblock_side_floats(n):
+        raise MgxError("gblock_fwd: activation buffer too small")
+    e0 = PROFILER.start() if PROFILER is not None else None
+    check(_lib().mgx_gblock_fwd_f32(C.byref(weights), _p(pack), _p(x), _p(y), _p(act), nimg, hl, wl, pos0, n,
+                                    K.stream_ptr()), "mgx_gblock_fwd_f32")
+    if e0 is not None:
+        PROFILER.stop("gblock_fwd_kernel<%s>" % ("true" if act is not None else "false"),
+                      GBLOCK_FLOP_PER_POSITION * n, e0,
+                      4.0 * (10 * n + (gblock_side_floats(n) if act is not None else 0)))
+
+
+def gblock_dgrad(weights, packt, dy, delta, dx, nimg, hl, wl, pos0=0, npos=0):
+    """dy (nimg,2hl,2wl,2) -> dx (nimg,hl,wl,2) for the positions of the range; `delta` receives the
+    intermediate gradients of the range."""
+    n = _gblock_range(nimg, hl, wl, pos0, npos)
     if dx.numel() != nimg * hl * wl * 2 or dy.numel() != 4 * dx.numel() or packt.numel() < gblock_packt_floats():
         raise MgxError("gblock_dgrad: size mismatch")
-    if delta.numel() < gblock_side_floats(nimg, hl, wl):
+    if delta.numel() < gblock_side_floats(n):
         raise MgxError("gblock_dgrad: gradient buffer too small")
     e0 = PROFILER.start() if PROFILER is not None else None
-    check(_lib().mgx_gblock_dgrad_f32(C.byref(weights), _p(packt), _p(dy), _p(delta), _p(dx), nimg, hl, wl,
+    check(_lib().mgx_gblock_dgrad_f32(C.byref(weights), _p(packt), _p(dy), _p(delta), _p(dx), nimg, hl, wl, pos0, n,
                                       K.stream_ptr()), "mgx_gblock_dgrad_f32")
     if e0 is not None:
-        PROFILER.stop("gblock_dgrad_kernel", GBLOCK_FLOP_PER_POSITION * nimg * hl * wl, e0,
-                      4.0 * (dx.numel() + dy.numel() + delta.numel()))
+        PROFILER.stop("gblock_dgrad_kernel", GBLOCK_FLOP_PER_POSITION * n, e0,
+                      4.0 * (10 * n + gblock_side_floats(n)))
 
 
-def gblock_wgrad(act, delta, grads, nimg, hl, wl):
-    """Adds the weight / bias gradients of the block into the tensors `grads` points to
-    (_cabi.GBlockWeights holding gradient pointers)."""
-    need = gblock_side_floats(nimg, hl, wl)
+def gblock_wgrad(act, delta, grads, npos):
+    """Adds the weight / bias gradients of the block, computed from the side buffers of `npos`
+    positions, into the tensors `grads` points to (_cabi.GBlockWeights holding gradient pointers)."""
+    need = gblock_side_floats(npos)
     if act.numel() < need or delta.numel() < need:
         raise MgxError("gblock_wgrad: side buffer too small")
-    nbytes = int(_lib().mgx_gblock_wgrad_workspace(nimg, hl, wl))
+    nbytes = int(_lib().mgx_gblock_wgrad_workspace_n(npos))
     ws = K.workspace(nbytes)
     e0 = PROFILER.start() if PROFILER is not None else None
-    check(_lib().mgx_gblock_wgrad_f32(_p(act), _p(delta), C.byref(grads), ws.data_ptr(), ws.numel(), nimg, hl, wl,
+    check(_lib().mgx_gblock_wgrad_f32(_p(act), _p(delta), C.byref(grads), ws.data_ptr(), ws.numel(), npos,
                                       K.stream_ptr()), "mgx_gblock_wgrad_f32")
     if e0 is not None:
-        PROFILER.stop("gblock_wgrad_kernel<*>", GBLOCK_FLOP_PER_POSITION * nimg * hl * wl, e0,
-                      4.0 * (act.numel() + delta.numel()))
+        PROFILER.stop("gblock_wgrad_kernel<*>", GBLOCK_FLOP_PER_POSITION * npos, e0, 8.0 * need)
 
 
 def upsample2x_fwd(x, y, nimg, h, w, c):

@@ -256,13 +256,15 @@ def test_micro_batching_reproduces_whole_batch_step():
             assert rel_l2(grads[k], v) < tol, "%s: %.3e" % (k, rel_l2(grads[k], v))
 
 
-@pytest.mark.parametrize("stage,fade,batch", [(1, False, 1), (1, True, 4), (2, True, 3)])
-def test_fused_generator_backward_matches_layerwise(stage, fade, batch):
+@pytest.mark.parametrize("stage,fade,batch,budget", [(1, False, 1, None), (1, True, 4, None), (2, True, 3, None),
+                                                     (2, True, 3, 48 << 20), (1, False, 1, 1 << 20)])
+def test_fused_generator_backward_matches_layerwise(stage, fade, batch, budget):
     """The fused grow-block kernels (saving forward, register-chained data gradient, tile-major
     weight gradients) against the layer-by-layer taped path on the same device: output abs 2e-5,
     every gradient tensor rel-L2 2e-5 (float32 summation order is the only difference).  Batch
-    1 and 3 leave the last 32-position tile partly empty."""
-    from music_generator_amd.graph import Model
+    1 and 3 leave the last 32-position tile partly empty; with a side-buffer budget the backward
+    re-computes the block's tensors over several position ranges."""
+    from music_generator_amd.graph import FusedGroup, Model
     n_blocks = stage + 1
     d, g, comp, W = build(n_blocks)
     model = g[stage][1 if fade else 0]
@@ -276,6 +278,7 @@ def test_fused_generator_backward_matches_layerwise(stage, fade, batch):
     results = []
     for fused in (False, True):
         Model.use_fused_backward = fused
+        FusedGroup.side_budget_bytes = budget
         try:
             model.bind_grads().zero_()
             y, tape = model.forward(z4[0], save=True)
@@ -283,6 +286,7 @@ def test_fused_generator_backward_matches_layerwise(stage, fade, batch):
             torch.cuda.synchronize()
         finally:
             Model.use_fused_backward = True
+            FusedGroup.side_budget_bytes = None
         results.append((y.cpu().numpy(), dz.cpu().numpy(),
                         {v.name: v.grad.cpu().numpy().copy() for v in model.trainable_variables}))
     (y0, dz0, g0), (y1, dz1, g1) = results

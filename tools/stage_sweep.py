@@ -14,8 +14,10 @@ import music_generator_amd as M
 STEP_GFLOP = [13.6, 59.9, 245.0, 985.0, 3947.0, 15794.0, 63182.0]
 # (batch, micro_batch) per stage: large batches at low resolution, memory-bounded micro-batches above
 PLAN = {0: (256, None), 1: (256, None), 2: (128, None), 3: (64, None), 4: (32, 16), 5: (16, 4), 6: (4, 4)}
-# generator backward chunk (samples): only where a micro-batch of generator activations does not fit
-GEN_CHUNK = {6: 1}
+# generator backward chunk (samples) and side-buffer budget (bytes) of the fused generator blocks:
+# only where a micro-batch of generator activations does not fit
+GEN_CHUNK = {}
+SIDE_BUDGET = {6: 8 << 30}
 
 ap = argparse.ArgumentParser()
 ap.add_argument("--stages", default="0,1,2,3,4,5")
@@ -33,6 +35,8 @@ for stage in [int(s) for s in args.stages.split(",")]:
     gan = M.define_composite(d, g, (1, 100, 2))[stage][1 if fade else 0]
     gan.micro_batch = mb
     gan.generator_chunk = GEN_CHUNK.get(stage)
+    from music_generator_amd.graph import FusedGroup
+    FusedGroup.side_budget_bytes = SIDE_BUDGET.get(stage)
     gan.set_train_steps(100)
     h, w = 4 << stage, 750 << stage
     real = torch.rand((batch, h, w, 2), device="cuda") * 2 - 1
@@ -44,6 +48,7 @@ for stage in [int(s) for s in args.stages.split(",")]:
     torch.cuda.synchronize()
     dt = (time.perf_counter() - t0) / args.steps
     print(json.dumps({"stage": stage, "hw": [h, w], "batch": batch, "micro_batch": mb, "generator_chunk": GEN_CHUNK.get(stage),
+                      "side_budget_gib": (SIDE_BUDGET[stage] >> 30) if stage in SIDE_BUDGET else None,
                       "fade_in": fade,
                       "ms_per_step": round(dt * 1e3, 2), "samples_per_s": round(batch / dt, 3),
                       "algorithmic_tflops": round(STEP_GFLOP[stage] * batch / dt / 1e3, 2),
