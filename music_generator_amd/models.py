@@ -585,7 +585,8 @@ class WGAN:
             flat_r = D.bind_grads(1)
             flat_r.zero_()
             sums = K.zeros((2,))
-            for idx in batches:
+            pending = None
+            for bi, idx in enumerate(batches):
                 zb, rb = self._take(z, idx), self._take(real, idx)
                 ones = self._ones(rb.shape[0])
                 fake, _ = G.forward(zb, save=False)
@@ -593,15 +594,21 @@ class WGAN:
                 del fake
                 D.bind_grads(0)
                 D.backward(tape, ones, need_input_grad=False)
+                if self.dist is not None and bi == len(batches) - 1:
+                    # the fake-pass gradient sums are final: their all-reduce runs on RCCL's stream
+                    # beside the real pass of this micro-batch (the combination below is linear, so
+                    # reducing the two unit-seed sums separately gives the reduced gradient)
+                    pending = self.dist.all_reduce_async(flat_f)
                 real_logits, tape = D.forward(rb, save=True)
                 D.bind_grads(1)
                 D.backward(tape, ones, need_input_grad=False)
                 del tape
                 ops.logit_sums(fake_logits.view(-1), real_logits.view(-1), sums, accumulate=True)
             out_d, cf, cr = self._finish_sums(sums, 0, n, True)
-            ops.combine_grads(flat_f, flat_f, flat_r, cf, cr)
             if self.dist is not None:
-                self.dist.all_reduce(flat_f)
+                self.dist.all_reduce(flat_r)
+                self.dist.wait_for(pending)
+            ops.combine_grads(flat_f, flat_f, flat_r, cf, cr)
             D.bind_grads(0)
             self.d_optimizer.apply_model_gradients(D)
 

@@ -52,8 +52,31 @@ class DataParallel:
     def all_reduce(self, t: torch.Tensor):
         """In-place sum over ranks, enqueued on the current stream (RCCL) / blocking (gloo)."""
         if self.world_size > 1:
-            dist.all_reduce(t, op=dist.ReduceOp.SUM)
+            if t.is_cuda and dist.get_backend() != "nccl":
+                # gloo rehearsal with device tensors: reduce a host copy
+                host = t.detach().cpu()
+                dist.all_reduce(host, op=dist.ReduceOp.SUM)
+                t.copy_(host)
+            else:
+                dist.all_reduce(t, op=dist.ReduceOp.SUM)
         return t
+
+    def all_reduce_async(self, t: torch.Tensor):
+        """Start an in-place sum over ranks that runs beside the kernels enqueued after this call
+        (RCCL uses its own stream, ordered after the work already on the current one).  Returns a
+        handle for wait_for(); None when there is nothing to do."""
+        if self.world_size > 1:
+            if dist.get_backend() != "nccl":      # gloo rehearsal: reduce in place now
+                self.all_reduce(t)
+                return None
+            return dist.all_reduce(t, op=dist.ReduceOp.SUM, async_op=True)
+        return None
+
+    @staticmethod
+    def wait_for(handle):
+        """Order the current stream behind an all_reduce_async (blocks the host only for gloo)."""
+        if handle is not None:
+            handle.wait()
 
     def shard(self, global_batch):
         idx = shard_indices(global_batch.shape[0], self.rank, self.world_size)

@@ -297,3 +297,31 @@ def test_fused_generator_backward_matches_layerwise(stage, fade, batch, budget):
             assert np.abs(g1[name]).max() < 1e-9, name
         else:
             assert rel_l2(g1[name], want) < 2e-5, "%s: %.3e" % (name, rel_l2(g1[name], want))
+
+
+def test_two_rank_device_step_equals_single_process(tmp_path):
+    """Two processes sharing the one GPU (gloo carries the collectives; RCCL needs one device per
+    rank) run the device train step on their MinibatchStdDev-group shards of a batch of 16 with the
+    overlapped gradient all-reduce; metrics (abs 1e-5) and the reduced D / G gradients (rel-L2 5e-5
+    / 2e-3 as for micro-batching) must equal the single-process step on the whole batch."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = os.path.join(root, "tests", "dp_worker.py")
+    single, multi = str(tmp_path / "single.npz"), str(tmp_path / "multi.npz")
+    env = dict(os.environ, MASTER_ADDR="127.0.0.1", MASTER_PORT="29631", OMP_NUM_THREADS="2")
+    out = subprocess.run([sys.executable, str(script), root, single], env=env, capture_output=True, text=True,
+                         timeout=100)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node=2", "--master-addr",
+           "127.0.0.1", "--master-port", "29631", str(script), root, multi]
+    out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=100)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    with np.load(single) as a, np.load(multi) as b:
+        for k in a.files:
+            if k.startswith("m|"):
+                assert abs(float(a[k]) - float(b[k])) < 1e-5, k
+            elif np.abs(a[k]).max() >= 1e-12:
+                name = k[2:]
+                tol = 5e-5 if not name.startswith(("dense_", "conv2d_transpose", "layer_norm", "weighted_sum_1")) else 2e-3
+                assert rel_l2(b[k], a[k]) < tol, "%s: %.3e" % (k, rel_l2(b[k], a[k]))
