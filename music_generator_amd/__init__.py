@@ -1,5 +1,7 @@
 """MI355X-native progressive-GAN training step (drop-in for trainer/models.py + the schedule of
-trainer/task.py of yefeza/music-generator).  See DESIGN.md at the repository root."""
+trainer/task.py of yefeza/music-generator): the Keras-like construction API in models.py / layers.py /
+graph.py, every numerical operation a call into libmgx.so (hand-written gfx950 kernels, C-ABI in
+include/mgx.h) through ops.py."""
 from . import backend  # noqa: F401
 from .backend import clear_session  # noqa: F401
 from .graph import Input, Model  # noqa: F401

@@ -2,16 +2,13 @@
 // convolutions (3x3 and 2x2, 32-channel chunks) on v_mfma_f32_32x32x2_f32, plus the dispatch
 // predicates shared with the forward / data-gradient tile kernel (tconv3.hip).
 //
-// A workgroup (4 waves) walks output tiles of TH=8 rows x TW=32 columns of one image.  The input
-// tile with its halo ((8+kh-1) x (32+kw-1) positions x 32 channels) is staged once into LDS with a
-// 36-float position stride (conflict-free ds_read_b128 along channels for 32 consecutive
-// positions); out-of-image positions are written as zeros, and the optional element-wise
-// multiplier (dY (.) f'(pre) for gradients) is applied while staging.  Forward / data-gradient:
-// every wave owns 2 rows (2 tiles of 32 positions), keeps the 32x32 weight slice of all taps in
-// registers (taps*16 VGPRs, lane half h holds k = 16h..16h+15 for column l&31) and issues
-// taps*16 MFMAs per tile from four 16-byte LDS reads per tap.  Inputs / outputs with 128 channels
-// are processed as four 32-channel chunks (accumulating over input chunks, or looping over
-// output chunks on the same staged tile).  The grid is persistent (<= 2 workgroups per CU).
+// A workgroup (4 waves, two workgroups per CU) walks output tiles of TH=8 rows x TW=32 columns of
+// one image.  The 32-channel input tile with its halo ((8+kh-1) x (32+kw-1) positions) and the
+// 32-channel output-gradient tile (multiplied by the saved activation derivative while staging)
+// go to LDS position-major; out-of-image positions are written as zeros.  Contraction runs over
+// positions, two per MFMA: a wave owns two tile rows and keeps one 32x32 accumulator per tap for
+// the whole launch; the grid is persistent and every wave writes one slab of partial sums that
+// conv_wgrad.hip adds in fixed order.  Input chunks of 128-channel convolutions are blockIdx.y.
 #include "common.h"
 #include "../../include/mgx.h"
 
