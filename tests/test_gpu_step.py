@@ -325,3 +325,31 @@ def test_two_rank_device_step_equals_single_process(tmp_path):
                 name = k[2:]
                 tol = 5e-5 if not name.startswith(("dense_", "conv2d_transpose", "layer_norm", "weighted_sum_1")) else 2e-3
                 assert rel_l2(b[k], a[k]) < tol, "%s: %.3e" % (k, rel_l2(b[k], a[k]))
+
+
+def test_progressive_schedule_two_stages():
+    """trainer/task.py:108-184 on the device with a tiny in-memory dataset: stage 0 fit, then the
+    stage-1 fade-in twin (alpha ramps 0 -> 1 over its steps) and the straight-through twin, which
+    share their layers: the fade-in phase must move the weights the straight phase then starts
+    from, every metric stays finite, and each phase runs int(n/batch)*epochs steps."""
+    from music_generator_amd import task
+    M.clear_session()
+    d, g, comp = task.build(2)
+    for pair in comp:
+        for gan in pair:
+            gan.seed(7)
+    w_before = g[1][0].trainable_variables[-1].numpy().copy()
+    hist = task.train(g, d, comp, task.synthetic_provider(8, seed=1), batch_sizes=[4, 4], epochs_norm=[2, 1],
+                      epochs_fade=[0, 3])
+    assert [len(h["ci_1"]) for h in hist] == [2, 3, 1]
+    for h in hist:
+        for k in ("delta_0", "cu_0", "ci_0", "delta_1", "cu_1", "ci_1"):
+            assert np.isfinite(h[k]).all(), k
+    fade, straight = comp[1][1], comp[1][0]
+    assert comp[0][0].actual_step == 2 * 2 and fade.actual_step == 2 * 3 and straight.actual_step == 2 * 1
+    assert fade.train_steps == 6
+    alphas = [float(l.alpha.numpy()) for l in fade.generator.layers if isinstance(l, M.WeightedSum)]
+    # the last fade-in step ran with alpha = (n-1)/(n-1) = 1, then Adam moved it by at most lr
+    assert all(abs(a - 1.0) <= 5e-4 + 1e-6 for a in alphas), alphas
+    assert np.abs(g[1][0].trainable_variables[-1].numpy() - w_before).max() > 0
+    assert g[1][0].layers[1] is g[1][1].layers[1]
