@@ -238,6 +238,11 @@ __global__ __launch_bounds__(512, 2) void tconv3_kernel(mgx_conv_desc d, const f
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
+        if (S > 1) __syncthreads();        // every wave is done with the weight slice
+        if (need_x) stage_write(xt + (cur ^ 1) * (NPIX * PSTR));
+        if (need_w) w_write();
+        // the stores of the epilogue come after the staging writes: the wait for the staged loads
+        // must not also wait for stores that were issued a moment ago
         if (kchunks == 1 || oc == S - 1) {
             if (late) {
                 pend = acc;
@@ -250,9 +255,6 @@ __global__ __launch_bounds__(512, 2) void tconv3_kernel(mgx_conv_desc d, const f
 #pragma unroll
             for (int reg = 0; reg < 16; ++reg) acc[reg] = 0.f;
         }
-        if (S > 1) __syncthreads();        // every wave is done with the weight slice
-        if (need_x) stage_write(xt + (cur ^ 1) * (NPIX * PSTR));
-        if (need_w) w_write();
         __syncthreads();
         if (need_x) cur ^= 1;
         t = tn;
