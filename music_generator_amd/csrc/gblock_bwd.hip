@@ -332,22 +332,25 @@ __host__ __device__ inline JobShape job_shape(int j) {
 }
 
 // sum over the job's slabs of accumulator element (tile, ci, co)
-__device__ __forceinline__ float slab_sum(const float* __restrict__ ws, const GJob& jb, int j, int tile, int ci, int co) {
+// Partial sums are taken by 8 cooperating threads per element (thread `sub` adds slabs sub, sub+8,
+// ...); gblock_unpack_kernel then adds the 8 partials in a fixed order.
+__device__ __forceinline__ float slab_sum(const float* __restrict__ ws, const GJob& jb, int j, int tile, int ci, int co,
+                                          int sub) {
     const JobShape sh = job_shape(j);
     const long stride = sh.ta * sh.tb * 1024L + sh.tb * 64L;
     const int lane = co + 32 * ((ci >> 2) & 1), reg = (ci & 3) + 4 * (ci >> 3);
     const float* p = ws + jb.ws_off + (tile * 16 + reg) * 64 + lane;
     float s = 0.f;
-    for (int sp = 0; sp < jb.nsplit; ++sp) s += p[sp * stride];
+    for (int sp = sub; sp < jb.nsplit; sp += 8) s += p[sp * stride];
     return s;
 }
 
-__device__ __forceinline__ float bias_sum(const float* __restrict__ ws, const GJob& jb, int j, int u, int col) {
+__device__ __forceinline__ float bias_sum(const float* __restrict__ ws, const GJob& jb, int j, int u, int col, int sub) {
     const JobShape sh = job_shape(j);
     const long stride = sh.ta * sh.tb * 1024L + sh.tb * 64L;
     const float* p = ws + jb.ws_off + sh.ta * sh.tb * 1024L + u * 64 + col;
     float s = 0.f;
-    for (int sp = 0; sp < jb.nsplit; ++sp) s += p[sp * stride] + p[sp * stride + 32];
+    for (int sp = sub; sp < jb.nsplit; sp += 8) s += p[sp * stride] + p[sp * stride + 32];
     return s;
 }
 
@@ -356,96 +359,106 @@ constexpr int N_PARAMS = 1024 + 128 + 6 * BR_PARAMS + 32768 + 256 + 16384 + 64 +
 
 __global__ __launch_bounds__(256) void gblock_unpack_kernel(mgx_gblock_grads g, GJobs jobs,
                                                             const float* __restrict__ ws) {
-    int e = blockIdx.x * 256 + threadIdx.x;
-    if (e >= N_PARAMS) return;
+    const int gt = blockIdx.x * 256 + threadIdx.x;
+    int e = gt >> 3;
+    const int sub = gt & 7;
+    const bool live = e < N_PARAMS;
+    if (!live) e = N_PARAMS - 1;          // keep the 8-lane groups whole for the shuffles below
     float* dst;
     float v;
     if (e < 1024) {                                   // K0 [tap][c][n]
         const int c = (e >> 7) & 1, n = e & 127;
         dst = g.k0 + e;
-        v = slab_sum(ws, jobs.j[38], 38, n >> 5, c, n & 31);
+        v = slab_sum(ws, jobs.j[38], 38, n >> 5, c, n & 31, sub);
     } else if ((e -= 1024) < 128) {                   // b0
         dst = g.b0 + e;
-        v = bias_sum(ws, jobs.j[38], 38, e >> 5, e & 31);
+        v = bias_sum(ws, jobs.j[38], 38, e >> 5, e & 31, sub);
     } else if ((e -= 128) < 6 * BR_PARAMS) {
         const int k = e / BR_PARAMS;
         e -= k * BR_PARAMS;
         if (e < 4096) {                               // K1 [a][co][ci]
             const int aco = e >> 7, ci = e & 127;
             dst = g.k1[k] + e;
-            v = slab_sum(ws, jobs.j[32 + k], 32 + k, ci >> 5, ci & 31, aco);
+            v = slab_sum(ws, jobs.j[32 + k], 32 + k, ci >> 5, ci & 31, aco, sub);
         } else if ((e -= 4096) < 16) {                // b1
             dst = g.b1[k] + e;
-            v = bias_sum(ws, jobs.j[32 + k], 32 + k, 0, e) + bias_sum(ws, jobs.j[32 + k], 32 + k, 0, 16 + e);
+            v = bias_sum(ws, jobs.j[32 + k], 32 + k, 0, e, sub) + bias_sum(ws, jobs.j[32 + k], 32 + k, 0, 16 + e, sub);
         } else if ((e -= 16) < 512) {                 // D1 [in 16][out 32]
             dst = g.d1[k] + e;
-            v = slab_sum(ws, jobs.j[14 + k], 14 + k, 0, e >> 5, e & 31);
+            v = slab_sum(ws, jobs.j[14 + k], 14 + k, 0, e >> 5, e & 31, sub);
         } else if ((e -= 512) < 32) {                 // c1
             dst = g.c1[k] + e;
-            v = bias_sum(ws, jobs.j[14 + k], 14 + k, 0, e);
+            v = bias_sum(ws, jobs.j[14 + k], 14 + k, 0, e, sub);
         } else if ((e -= 32) < 4096) {                // K2 [b][co][ci]
             const int b = e >> 11, co = (e >> 5) & 63, ci = e & 31;
             const int j = 20 + k * 2 + b;
             dst = g.k2[k] + e;
-            v = slab_sum(ws, jobs.j[j], j, co >> 5, ci, co & 31);
+            v = slab_sum(ws, jobs.j[j], j, co >> 5, ci, co & 31, sub);
         } else if ((e -= 4096) < 64) {                // b2
             const int j = 20 + k * 2;
             dst = g.b2[k] + e;
-            v = bias_sum(ws, jobs.j[j], j, e >> 5, e & 31) + bias_sum(ws, jobs.j[j + 1], j + 1, e >> 5, e & 31);
+            v = bias_sum(ws, jobs.j[j], j, e >> 5, e & 31, sub) + bias_sum(ws, jobs.j[j + 1], j + 1, e >> 5, e & 31, sub);
         } else if ((e -= 64) < 8192) {                // D2 [in 64][out 128]
             const int in = e >> 7, out = e & 127;
             dst = g.d2[k] + e;
-            v = slab_sum(ws, jobs.j[4 + k], 4 + k, (in >> 5) * 4 + (out >> 5), in & 31, out & 31);
+            v = slab_sum(ws, jobs.j[4 + k], 4 + k, (in >> 5) * 4 + (out >> 5), in & 31, out & 31, sub);
         } else {                                      // c2: the Add hands every branch the same gradient
             e -= 8192;
             dst = g.c2[k] + e;
-            v = bias_sum(ws, jobs.j[4], 4, e >> 5, e & 31);
+            v = bias_sum(ws, jobs.j[4], 4, e >> 5, e & 31, sub);
         }
     } else if ((e -= 6 * BR_PARAMS) < 32768) {        // W1 [in 128][out 256]
         const int in = e >> 8, out = e & 255;
         const int j = (in >> 6) * 2 + (out >> 7);
         dst = g.w1 + e;
-        v = slab_sum(ws, jobs.j[j], j, ((in & 63) >> 5) * 4 + ((out & 127) >> 5), in & 31, out & 31);
+        v = slab_sum(ws, jobs.j[j], j, ((in & 63) >> 5) * 4 + ((out & 127) >> 5), in & 31, out & 31, sub);
     } else if ((e -= 32768) < 256) {                  // e1
         const int j = e >> 7;
         dst = g.e1 + e;
-        v = bias_sum(ws, jobs.j[j], j, (e & 127) >> 5, e & 31);
+        v = bias_sum(ws, jobs.j[j], j, (e & 127) >> 5, e & 31, sub);
     } else if ((e -= 256) < 16384) {                  // W2 [in 256][out 64]
         const int in = e >> 6, out = e & 63;
         const int j = 10 + (in >> 7);
         dst = g.w2 + e;
-        v = slab_sum(ws, jobs.j[j], j, ((in & 127) >> 5) * 2 + (out >> 5), in & 31, out & 31);
+        v = slab_sum(ws, jobs.j[j], j, ((in & 127) >> 5) * 2 + (out >> 5), in & 31, out & 31, sub);
     } else if ((e -= 16384) < 64) {                   // e2
         dst = g.e2 + e;
-        v = bias_sum(ws, jobs.j[10], 10, e >> 5, e & 31);
+        v = bias_sum(ws, jobs.j[10], 10, e >> 5, e & 31, sub);
     } else if ((e -= 64) < 512) {                     // W3 [in 64][out 8]
         const int in = e >> 3, out = e & 7;
         dst = g.w3 + e;
-        v = slab_sum(ws, jobs.j[12], 12, in >> 5, in & 31, out);
+        v = slab_sum(ws, jobs.j[12], 12, in >> 5, in & 31, out, sub);
     } else if ((e -= 512) < 8) {                      // e3
         dst = g.e3 + e;
-        v = bias_sum(ws, jobs.j[12], 12, 0, e);
+        v = bias_sum(ws, jobs.j[12], 12, 0, e, sub);
     } else if ((e -= 8) < 16) {                       // W4 [in 8][out 2]
         dst = g.w4 + e;
-        v = slab_sum(ws, jobs.j[13], 13, 0, e >> 1, e & 1);
+        v = slab_sum(ws, jobs.j[13], 13, 0, e >> 1, e & 1, sub);
     } else {                                          // e4
         e -= 16;
         dst = g.e4 + e;
-        v = bias_sum(ws, jobs.j[13], 13, 0, e);
+        v = bias_sum(ws, jobs.j[13], 13, 0, e, sub);
     }
-    *dst += v;
+    float total = 0.f;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) total += __shfl(v, (threadIdx.x & ~7) + k, 64);
+    if (live && sub == 0) *dst += total;
 }
 
 // launches per accumulator shape: first job, number of jobs
 struct ShapeRun {
     int ta, tb, job0, njobs;
+    int wg_per_cu;      // resident workgroups per CU at the kernel's register use
 };
-const ShapeRun kRuns[7] = {{2, 4, 0, 10}, {4, 2, 10, 2}, {2, 1, 12, 1}, {1, 1, 13, 7}, {1, 2, 20, 12}, {4, 1, 32, 6},
-                           {1, 4, 38, 1}};
+const ShapeRun kRuns[7] = {{2, 4, 0, 10, 1}, {4, 2, 10, 2, 1}, {2, 1, 12, 1, 3}, {1, 1, 13, 7, 5}, {1, 2, 20, 12, 3},
+                           {4, 1, 32, 6, 2}, {1, 4, 38, 1, 2}};
 
-int grid_x(long ntiles, int njobs) {
+// workgroups per job: the jobs of a launch together fill the chip's resident slots exactly once (a
+// partly filled second round would idle most CUs), at most 256 per job (1024 slabs)
+int grid_x(long ntiles, const ShapeRun& run) {
     long x = (ntiles + 3) / 4;
-    const long cap = njobs >= 8 ? 48 : 64;
+    long cap = (256L * run.wg_per_cu) / run.njobs;
+    if (cap > 256) cap = 256;
     if (x > cap) x = cap;
     return (int)(x < 1 ? 1 : x);
 }
@@ -470,7 +483,7 @@ long build_jobs(GJobs& J, long ntiles) {
     set(38, GB_X, GB_F, 1, 0, 0, 1);
     long off = 0;
     for (const ShapeRun& run : kRuns) {
-        const int nsplit = grid_x(ntiles, run.njobs) * 4;
+        const int nsplit = grid_x(ntiles, run) * 4;
         for (int j = run.job0; j < run.job0 + run.njobs; ++j) {
             J.j[j].nsplit = nsplit;
             J.j[j].ws_off = off;
@@ -483,7 +496,7 @@ long build_jobs(GJobs& J, long ntiles) {
 template <int TA, int TB>
 void launch_wgrad(const ShapeRun& run, const float* act, const float* delta, const GJobs& J, float* ws, long ntiles,
                   hipStream_t st) {
-    dim3 grid(grid_x(ntiles, run.njobs), run.njobs);
+    dim3 grid(grid_x(ntiles, run), run.njobs);
     hipLaunchKernelGGL((gblock_wgrad_kernel<TA, TB>), grid, dim3(256), 0, st, act, delta, J, run.job0, ws, ntiles);
 }
 
@@ -546,6 +559,6 @@ extern "C" int mgx_gblock_wgrad_f32(const float* act, const float* delta, const 
     launch_wgrad<1, 2>(kRuns[4], act, delta, J, ws, ntiles, st);
     launch_wgrad<4, 1>(kRuns[5], act, delta, J, ws, ntiles, st);
     launch_wgrad<1, 4>(kRuns[6], act, delta, J, ws, ntiles, st);
-    hipLaunchKernelGGL(gblock_unpack_kernel, dim3((N_PARAMS + 255) / 256), dim3(256), 0, st, g, J, ws);
+    hipLaunchKernelGGL(gblock_unpack_kernel, dim3((N_PARAMS * 8 + 255) / 256), dim3(256), 0, st, g, J, ws);
     return mgx_launch_status();
 }
