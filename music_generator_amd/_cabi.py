@@ -11,7 +11,7 @@ import os
 _HERE = os.path.dirname(os.path.abspath(__file__))
 LIB_PATH = os.path.join(_HERE, "libmgx.so")
 
-MGX_OK = 0
+MGX_OK, MGX_ERR_ARG, MGX_ERR_LAUNCH, MGX_ERR_WORKSPACE = 0, 1, 2, 3      # status codes of include/mgx.h
 _ERR = {1: "bad argument", 2: "kernel launch failure", 3: "workspace too small"}
 
 

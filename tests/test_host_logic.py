@@ -214,3 +214,43 @@ def test_two_rank_gloo_data_parallel_equals_single_process(tmp_path):
     out = subprocess.run(cmd, env=env, capture_output=True, text=True, timeout=600)
     assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
     assert "DP-OK" in out.stdout
+
+
+def test_cabi_rejects_bad_arguments_before_touching_the_device():
+    """Argument validation of the entry points happens on the host, before any launch: null
+    pointers, inconsistent descriptors, short workspaces and misaligned position ranges return
+    the documented status codes (no GPU needed to observe them)."""
+    lib = _cabi.load()
+    d = _cabi.ConvDesc()
+    for k, v in dict(nimg=1, hin=8, win=32, cin=32, hout=8, wout=32, kh=3, kw=3, sh=1, sw=1, pt=1, pl=1, flip=0,
+                     ngemm=32, dkh=1, dkw=1, cout=32, wsk=32, wsn=1, wtap=1024, nbias=32, accumulate=0).items():
+        setattr(d, k, v)
+    d.act_alpha = 0.0
+    assert lib.mgx_conv_gemm_f32(ctypes.byref(d), None, None, None, None, None, None, None) == _cabi.MGX_ERR_ARG
+    bad = _cabi.ConvDesc.from_buffer_copy(d)
+    bad.ngemm = 48                                       # != dkh*dkw*cout
+    fake = ctypes.c_void_p(4096)                         # never dereferenced: validation fails first
+    assert lib.mgx_conv_gemm_f32(ctypes.byref(bad), fake, None, fake, fake, fake, None, None) == _cabi.MGX_ERR_ARG
+    assert lib.mgx_conv_wgrad_workspace(None) < 0
+    need = lib.mgx_conv_wgrad_workspace(ctypes.byref(d))
+    assert need > 0
+    assert lib.mgx_conv_wgrad_f32(ctypes.byref(d), fake, fake, None, fake, fake, fake, need - 1, None) \
+        == _cabi.MGX_ERR_WORKSPACE
+    assert lib.mgx_conv_route(ctypes.byref(d), 0) == 1 and lib.mgx_conv_route(ctypes.byref(d), 1) == 1
+    d.hin = d.hout = 4                                   # not a multiple of the 8-row tile
+    assert lib.mgx_conv_route(ctypes.byref(d), 0) == 0
+    # fused generator block: unset weight pointers, misaligned range, short workspace
+    w = _cabi.GBlockWeights()
+    assert lib.mgx_gblock_fwd_f32(ctypes.byref(w), fake, fake, fake, None, 1, 4, 750, 0, 0, None) == _cabi.MGX_ERR_ARG
+    for name, _ in _cabi.GBlockWeights._fields_:
+        cur = getattr(w, name)
+        if isinstance(cur, ctypes.Array):
+            for i in range(len(cur)):
+                cur[i] = 4096
+        else:
+            setattr(w, name, 4096)
+    assert lib.mgx_gblock_fwd_f32(ctypes.byref(w), fake, fake, fake, None, 1, 4, 750, 64, 0, None) == _cabi.MGX_ERR_ARG
+    assert lib.mgx_gblock_dgrad_f32(ctypes.byref(w), fake, fake, fake, fake, 1, 4, 750, 3000, 0, None) \
+        == _cabi.MGX_ERR_ARG
+    assert lib.mgx_gblock_wgrad_f32(fake, fake, ctypes.byref(w), fake, 16, 3000, None) == _cabi.MGX_ERR_WORKSPACE
+    assert lib.mgx_gblock_side_floats(1, 4, 750) == lib.mgx_gblock_side_floats_n(3000) == 24 * 4 * 4104 * 32
