@@ -163,7 +163,7 @@ int tile_grid(long ntiles) {
 
 // Is this contraction a stride-1 'same' conv the tile kernels cover?
 bool mgx_tconv_applicable(const mgx_conv_desc& d) {
-    if (d.kh != d.kw || (d.kh != 2 && d.kh != 3)) return false;
+    if (d.kh != d.kw || d.kh < 1 || d.kh > 3) return false;
     if (d.sh != 1 || d.sw != 1 || d.dkh != 1 || d.dkw != 1) return false;
     if (d.hout != d.hin || d.wout != d.win) return false;
     if (d.pt < 0 || d.pt >= d.kh || d.pl < 0 || d.pl >= d.kw) return false;
@@ -175,9 +175,9 @@ bool mgx_tconv_applicable(const mgx_conv_desc& d) {
     if ((long)(TH + 2) * d.win * (d.cin > d.ngemm ? d.cin : d.ngemm) * 4 >= (1L << 31)) return false;
     if ((long)d.nimg * (d.hin / TH) * ((d.win + TW - 1) / TW) >= (1L << 31)) return false;
     if (d.nbias != 0 && d.nbias != d.ngemm) return false;
-    // weight strides the kernels hard-code: [k][n] rows of 32 (forward) or [n][k] rows of 32 (data-gradient)
-    const bool kn = d.wsk == 32 && d.wsn == 1 && d.ngemm == 32;
-    const bool nk = d.wsk == 1 && d.wsn == 32 && d.cin == 32;
+    // dense weight slices per tap: [k][n] rows (forward) or [n][k] rows (data-gradient)
+    const bool kn = d.wsn == 1 && d.wsk == d.ngemm;
+    const bool nk = d.wsk == 1 && d.wsn == d.cin;
     if (!kn && !nk) return false;
     if (d.wtap != (int64_t)d.cin * d.ngemm) return false;
     return true;
@@ -192,7 +192,9 @@ int mgx_tconv_launch(const mgx_conv_desc& d, const float* x, const float* xmul, 
 }
 
 // weight gradient: same applicability on the FORWARD descriptor, output channels must be 32
-bool mgx_twgrad_applicable(const mgx_conv_desc& d) { return mgx_tconv_applicable(d) && d.ngemm == 32 && d.flip == 0; }
+bool mgx_twgrad_applicable(const mgx_conv_desc& d) {
+    return mgx_tconv_applicable(d) && d.kh >= 2 && d.ngemm == 32 && d.flip == 0;
+}
 
 bool mgx_pointwise2_applicable(const mgx_conv_desc& d);   // conv_gemm.hip
 

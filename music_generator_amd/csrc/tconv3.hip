@@ -1,4 +1,4 @@
-// Stride-1 'same' convolution (3x3 / 2x2) of one 32-channel input slice into one 32-channel
+// Stride-1 'same' convolution (3x3 / 2x2 / 1x1) of one 32-channel input slice into one 32-channel
 // output slice on v_mfma_f32_32x32x2_f32 — forward and data-gradient of the discriminator convs.
 //
 // One workgroup of 8 waves per CU walks tiles of 8 rows x 32 columns; wave w owns row w (one
@@ -57,10 +57,10 @@ __global__ __launch_bounds__(512, 2) void tconv3_kernel(mgx_conv_desc d, const f
             const int tap = i >> 8, kq = (i >> 5) & 7, n = i & 31;
             const int wt = d.flip ? (TAPS - 1 - tap) : tap;
             const float* wp = w + (long)wt * d.wtap + woff;
-            if (WT) wreg[it] = *(const f32x4*)(wp + n * 32 + kq * 4);          // [n][k], rows of 32
+            if (WT) wreg[it] = *(const f32x4*)(wp + (long)n * d.wsn + kq * 4);          // [n][k] rows
             else {
 #pragma unroll
-                for (int j = 0; j < 4; ++j) wreg[it][j] = wp[(kq * 4 + j) * 32 + n];   // [k][n], rows of 32
+                for (int j = 0; j < 4; ++j) wreg[it][j] = wp[(long)(kq * 4 + j) * d.wsk + n];   // [k][n] rows
             }
         }
     };
@@ -294,6 +294,7 @@ void launch3(const mgx_conv_desc& d, const float* x, const float* xmul, const fl
 int mgx_tconv3_launch(const mgx_conv_desc& d, const float* x, const float* xmul, const float* w, const float* bias,
                       float* y, float* dact, hipStream_t st) {
     if (d.kh == 3) launch3<3, 3>(d, x, xmul, w, bias, y, dact, st);
-    else launch3<2, 2>(d, x, xmul, w, bias, y, dact, st);
+    else if (d.kh == 2) launch3<2, 2>(d, x, xmul, w, bias, y, dact, st);
+    else launch3<1, 1>(d, x, xmul, w, bias, y, dact, st);
     return mgx_launch_status();
 }
