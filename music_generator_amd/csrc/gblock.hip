@@ -269,6 +269,7 @@ __global__ __launch_bounds__(256, 1) void gblock_fwd_kernel(const float* __restr
     float* yrow0 = store_y ? y + ((row * 2) * (2L * wl) + 2L * j) * 2 : nullptr;      // output row 2i, column 2j
     float* yrow1 = store_y ? yrow0 + (2L * wl) * 2 : nullptr;                         // output row 2i+1
     WBuf B;
+    B.touch[0] = B.touch[1] = 0.f;
     pf<0, 16>(B, fptr(pack, OFF_F), lane);
     half_block<0, 0, false, SAVE>(pack, x0, lane, h, pvalid, yrow0, B, fptr(pack, OFF_F), atile);
     half_block<1, 1, true, SAVE>(pack, x0, lane, h, pvalid, yrow1, B, nullptr, atile);
@@ -276,7 +277,7 @@ __global__ __launch_bounds__(256, 1) void gblock_fwd_kernel(const float* __restr
 
 }  // namespace
 
-extern "C" int64_t mgx_gblock_pack_floats(void) { return PACK_FLOATS; }
+extern "C" int64_t mgx_gblock_pack_floats(void) { return PACK_FLOATS + FRAG_SLACK; }
 
 extern "C" int64_t mgx_gblock_side_floats_n(int64_t npos) {
     return npos <= 0 ? 0 : ((npos + 127) / 128) * 4 * (GB_ROWS * 32L);

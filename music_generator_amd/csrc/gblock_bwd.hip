@@ -110,6 +110,7 @@ __global__ __launch_bounds__(256, 1) void gblock_dgrad_kernel(const float* __res
     const float* dy0 = dy + ((row * 2) * (2L * wl) + 2L * j) * 2 + h;     // output row 2i, column 2j, channel h
     float* dt = delta + tile * (GB_ROWS * 32L);
     WBuf B;
+    B.touch[0] = B.touch[1] = 0.f;
     f32x16 dF[4];
 #pragma unroll
     for (int it = 0; it < 4; ++it) zero(dF[it]);
@@ -509,7 +510,7 @@ bool all_set(const void* strukt, size_t bytes) {
 
 }  // namespace
 
-extern "C" int64_t mgx_gblock_packt_floats(void) { return PACKT_FLOATS; }
+extern "C" int64_t mgx_gblock_packt_floats(void) { return PACKT_FLOATS + FRAG_SLACK; }
 
 extern "C" int64_t mgx_gblock_wgrad_workspace_n(int64_t npos) {
     if (npos <= 0) return 0;

@@ -11,10 +11,24 @@ __device__ __forceinline__ int chan(int s, int h) { return (s & 3) + 8 * (s >> 2
 
 struct WBuf {
     float v[2][16];
+    float touch[2];   // destinations of the look-ahead reads of pf(); set to 0 before the first pf()
 };
+
+// Packed fragment buffers carry this many floats of slack behind their last fragment so that the
+// look-ahead read below never leaves the allocation.
+constexpr int FRAG_SLACK = 2048;
 
 template <int P, int NS>
 __device__ __forceinline__ void pf(WBuf& B, const float* __restrict__ frag, int lane) {
+    if (NS == 16) {
+        // Pull the 4 KiB behind this group (the group that most often follows it) towards the CU's
+        // L1: every lane reads one dword of one of its 32 cache lines and drops it.  Issued one
+        // group before the real loads of that data, it turns their L2 latency into an L1 hit.
+        // The look-ahead value read two groups ago is "used" here (an empty asm), which keeps its
+        // register reserved until that load has returned.
+        asm volatile("" ::"v"(B.touch[P]));
+        B.touch[P] = frag[16 * FR + (lane & 31) * 32];
+    }
 #pragma unroll
     for (int s = 0; s < NS; ++s) B.v[P][s] = frag[s * FR + lane];
 }
