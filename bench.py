@@ -72,6 +72,8 @@ def main():
     ap.add_argument("--batch", type=int, default=64, help="per-GPU batch")
     ap.add_argument("--straight", action="store_true", help="straight-through twin instead of fade-in")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--reuse-real-logits", action="store_true",
+                    help="evaluate discriminator(real) once after the D update instead of three times (same values)")
     ap.add_argument("--cpu-sample-batch", type=int, default=2)
     args = ap.parse_args()
 
@@ -99,6 +101,7 @@ def main():
     comp = M.define_composite(d, g, (1, 100, 2))
     gan = comp[stage][1 if fade else 0]
     gan.dist = dist
+    gan.reuse_real_logits = args.reuse_real_logits
     if dist is not None:
         dist.broadcast_weights(gan.discriminator, gan.generator)
     gan.set_train_steps(100)
@@ -155,7 +158,8 @@ def main():
            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
            "config": {"workload": "stage-%d (%dx%d) %s G+D train step, batch %d per GPU, fp32"
                                   % (stage, h, w, "fade-in" if fade else "straight-through", args.batch),
-                      "global_batch": global_batch, "parallelism": "dp%d" % world},
+                      "global_batch": global_batch, "parallelism": "dp%d" % world,
+                      "discriminator_real_passes_per_step": 2 if args.reuse_real_logits else 4},
            "roofline": roofline, "last_metrics": last}
     if world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(stage, fade, args.cpu_sample_batch, n_blocks)

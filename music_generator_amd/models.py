@@ -464,6 +464,11 @@ class WGAN:
         self.last_losses = None
         self.micro_batch = None               # samples per micro-batch (multiple of 4); None = whole batch
         self.generator_chunk = None           # samples per generator backward chunk (see train_step)
+        # models.py:126, 141 and 152 evaluate discriminator(real_images) three times with the same
+        # weights (the discriminator only changes in its own update).  True evaluates it once and
+        # re-uses the logit sum: same values bit for bit, two discriminator forwards less per step.
+        # Off by default so that a step runs every pass the reference runs.
+        self.reuse_real_logits = False
         self._mb_cache: Dict = {}
         self._ones_cache: Dict = {}
         self._latents: List = []
@@ -544,15 +549,18 @@ class WGAN:
         ops.wgan_loss(sums, n_global, mode, out4, dfake, dreal, 1 if want_coef else 0)
         return out4, dfake, dreal
 
-    def _metric_block(self, real, n, batches):
-        """models.py:124-130 / 150-156: fresh latents, forward only."""
+    def _metric_block(self, real, n, batches, real_sum=None):
+        """models.py:124-130 / 150-156: fresh latents, forward only.  `real_sum` (1 float on the
+        device) replaces the real pass with an already known sum of real logits."""
         D, G = self.discriminator, self.generator
         z = self._draw(n)
         sums = K.zeros((2,))
         for idx in batches:
             fake_logits = D(G(self._take(z, idx)))
-            real_logits = D(self._take(real, idx))
-            ops.logit_sums(fake_logits.view(-1), real_logits.view(-1), sums, accumulate=True)
+            real_logits = D(self._take(real, idx)).view(-1) if real_sum is None else None
+            ops.logit_sums(fake_logits.view(-1), real_logits, sums, accumulate=True)
+        if real_sum is not None:
+            sums[1:2].copy_(real_sum)
         out4, _, _ = self._finish_sums(sums, 0, n, False)
         return out4
 
@@ -613,7 +621,13 @@ class WGAN:
             self.d_optimizer.apply_model_gradients(D)
 
         # ---- metric block 0 ----
-        m0 = self._metric_block(real, n, batches)
+        real_sum = None
+        if self.reuse_real_logits:
+            rs = K.zeros((2,))
+            for idx in batches:
+                ops.logit_sums(None, D(self._take(real, idx)).view(-1), rs, accumulate=True)
+            real_sum = rs[1:2].clone()           # local sum; the all-reduce happens with the fake sums
+        m0 = self._metric_block(real, n, batches, real_sum)
 
         # ---- generator update ----
         z = self._draw(n)
@@ -640,8 +654,10 @@ class WGAN:
                     _, tape_g = G.forward(zb[s0:s0 + chunk], save=True)
                     G.backward(tape_g, dgen[s0:s0 + chunk], need_input_grad=False)
             del tape_g, dgen
-            real_logits = D(rb)
-            ops.logit_sums(gen_logits.view(-1), real_logits.view(-1), sums, accumulate=True)
+            real_logits = D(rb).view(-1) if real_sum is None else None
+            ops.logit_sums(gen_logits.view(-1), real_logits, sums, accumulate=True)
+        if real_sum is not None:
+            sums[1:2].copy_(real_sum)
         out_g, cf, _ = self._finish_sums(sums, 1, n, True)
         ops.combine_grads(flat_g, flat_g, None, cf, None)
         if self.dist is not None:
@@ -649,7 +665,7 @@ class WGAN:
         self.g_optimizer.apply_model_gradients(G)
 
         # ---- metric block 1 ----
-        m1 = self._metric_block(real, n, batches)
+        m1 = self._metric_block(real, n, batches, real_sum)
 
         self.actual_step += 1
         self.last_losses = {"d_loss": out_d[0], "g_loss": out_g[0]}

@@ -230,10 +230,12 @@ def test_micro_batching_reproduces_whole_batch_step():
     n_blocks, stage, batch = 2, 1, 16
     real, z4 = R.synthetic_inputs(stage, batch, seed=5)
     results = []
-    for mb in (None, 4, 8, (8, 2)):
+    for mb in (None, 4, 8, (8, 2), (8, "reuse")):
         d, g, comp, W = build(n_blocks)
         gan = comp[stage][1]
-        if isinstance(mb, tuple):            # (micro-batch, generator backward chunk)
+        if isinstance(mb, tuple) and mb[1] == "reuse":      # one evaluation of D(real) after the D update
+            mb, gan.reuse_real_logits = mb[0], True
+        elif isinstance(mb, tuple):                         # (micro-batch, generator backward chunk)
             mb, gan.generator_chunk = mb
         gan.micro_batch = mb
         gan.set_train_steps(11)
