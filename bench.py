@@ -141,6 +141,11 @@ def main():
     global_batch = args.batch * world
     value = global_batch * args.steps / elapsed
     summ = prof.summary()
+    # bandwidth-bound kernels (zero FLOPs recorded): achieved GB/s against the 8 TB/s HBM peak
+    hbm_ops = {k: {"launches": v[0], "ms": round(v[1], 3), "GB/s": round(v[3] / v[1] / 1e6, 1),
+                   "frac_of_8TBps": round(v[3] / v[1] / 1e6 / 8000.0, 3)}
+               for k, v in summ.items() if v[2] == 0.0 and v[1] > 0}
+    summ = {k: v for k, v in summ.items() if v[2] > 0.0}
     key, (launches, ms, flops, nbytes) = max(summ.items(), key=lambda kv: kv[1][1])
     achieved = flops / (ms * 1e-3) / 1e12
     contraction_ms = sum(v[1] for v in summ.values())
@@ -160,7 +165,7 @@ def main():
                                   % (stage, h, w, "fade-in" if fade else "straight-through", args.batch),
                       "global_batch": global_batch, "parallelism": "dp%d" % world,
                       "discriminator_real_passes_per_step": 2 if args.reuse_real_logits else 4},
-           "roofline": roofline, "last_metrics": last}
+           "roofline": roofline, "hbm_ops": hbm_ops, "last_metrics": last}
     if world == 1 and not args.no_cpu_baseline:
         out["cpu_baseline"] = cpu_baseline(stage, fade, args.cpu_sample_batch, n_blocks)
     print(json.dumps(out))

@@ -55,6 +55,29 @@ class LaunchProfiler:
 PROFILER: Optional[LaunchProfiler] = None
 
 
+def _hbm_op(name):
+    """Decorator for the wrappers of bandwidth-bound kernels: when a LaunchProfiler is active the call
+    is timed and the bytes of its tensor arguments (each read or written once, the algorithmic
+    traffic) are recorded under `name` with zero FLOPs."""
+    def deco(fn):
+        def wrapped(*args, **kw):
+            if PROFILER is None:
+                return fn(*args, **kw)
+            nbytes = 0.0
+            for a in list(args) + list(kw.values()):
+                if isinstance(a, torch.Tensor):
+                    nbytes += a.numel() * a.element_size()
+                elif isinstance(a, (list, tuple)):
+                    nbytes += sum(t.numel() * t.element_size() for t in a if isinstance(t, torch.Tensor))
+            e0 = PROFILER.start()
+            out = fn(*args, **kw)
+            PROFILER.stop(name, 0.0, e0, nbytes)
+            return out
+        wrapped.__name__, wrapped.__doc__ = fn.__name__, fn.__doc__
+        return wrapped
+    return deco
+
+
 def _gemm_key(d: ConvDesc, mul: bool = False) -> str:
     route = _lib().mgx_conv_route(C.byref(d), 0)
     if route == 2 and not mul:
@@ -232,6 +255,7 @@ def gblock_wgrad(act, delta, grads, npos):
         PROFILER.stop("gblock_wgrad_kernel<*>", GBLOCK_FLOP_PER_POSITION * npos, e0, 8.0 * need)
 
 
+@_hbm_op("upsample_fwd")
 def upsample2x_fwd(x, y, nimg, h, w, c):
     if x.numel() != nimg * h * w * c or y.numel() != 4 * x.numel():
         raise MgxError("upsample2x_fwd: size mismatch")
@@ -245,6 +269,7 @@ def upsample2x_bwd(dy, dx, nimg, h, w, c, accumulate):
           "mgx_upsample2x_bwd")
 
 
+@_hbm_op("avgpool_fwd")
 def avgpool2x_fwd(x, y, nimg, h, w, c):
     if x.numel() != nimg * h * w * c or 4 * y.numel() != x.numel():
         raise MgxError("avgpool2x_fwd: size mismatch")
@@ -258,6 +283,7 @@ def avgpool2x_bwd(dy, dx, nimg, h, w, c, accumulate):
           "mgx_avgpool2x_bwd")
 
 
+@_hbm_op("add_n")
 def add_n(xs: Sequence[torch.Tensor], y):
     n = y.numel()
     if not 1 <= len(xs) <= 8 or any(t.numel() != n for t in xs):
@@ -272,6 +298,7 @@ def add_inplace(dst, src):
     check(_lib().mgx_add_inplace(_p(dst), _p(src), dst.numel(), K.stream_ptr()), "mgx_add_inplace")
 
 
+@_hbm_op("wsum_fwd")
 def weighted_sum_fwd(a, b, alpha, y):
     if a.numel() != b.numel() or a.numel() != y.numel() or alpha.numel() != 1:
         raise MgxError("weighted_sum_fwd: size mismatch")
@@ -279,6 +306,7 @@ def weighted_sum_fwd(a, b, alpha, y):
           "mgx_weighted_sum_fwd")
 
 
+@_hbm_op("wsum_bwd")
 def weighted_sum_bwd(dy, a, b, alpha, da, acc_a, db, acc_b, dalpha):
     n = dy.numel()
     for t in (a, b, da, db):
@@ -291,6 +319,7 @@ def weighted_sum_bwd(dy, a, b, alpha, da, acc_a, db, acc_b, dalpha):
           "mgx_weighted_sum_bwd")
 
 
+@_hbm_op("layernorm_fwd")
 def layernorm_fwd(x, gamma, beta, y, stats, nimg, e, eps):
     if x.numel() != nimg * e or y.numel() != nimg * e or gamma.numel() != e or beta.numel() != e \
             or stats.numel() != 2 * nimg:
@@ -301,6 +330,7 @@ def layernorm_fwd(x, gamma, beta, y, stats, nimg, e, eps):
                                 ws.data_ptr(), ws.numel(), K.stream_ptr()), "mgx_layernorm_fwd")
 
 
+@_hbm_op("layernorm_bwd")
 def layernorm_bwd(dy, x, gamma, stats, dx, acc_x, dgamma, dbeta, nimg, e):
     if dy.numel() != nimg * e or x.numel() != nimg * e or gamma.numel() != e or stats.numel() != 2 * nimg:
         raise MgxError("layernorm_bwd: size mismatch")
@@ -313,6 +343,7 @@ def layernorm_bwd(dy, x, gamma, stats, dx, acc_x, dgamma, dbeta, nimg, e):
                                 nimg, e, ws.data_ptr(), ws.numel(), K.stream_ptr()), "mgx_layernorm_bwd")
 
 
+@_hbm_op("mbstd_fwd")
 def mbstd_fwd(x, y, stat, n, h, w, c):
     e = h * w * c
     g = min(4, n)
@@ -324,6 +355,7 @@ def mbstd_fwd(x, y, stat, n, h, w, c):
           "mgx_mbstd_fwd")
 
 
+@_hbm_op("mbstd_bwd")
 def mbstd_bwd(dy, x, dx, n, h, w, c):
     e = h * w * c
     if x.numel() != n * e or dx.numel() != n * e or dy.numel() != n * (e + w * c):
