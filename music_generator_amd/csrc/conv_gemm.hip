@@ -7,10 +7,15 @@
 // order in which k is consumed is free, so step j of a chunk pairs k0+j (lanes 0-31) with
 // k0+4+j (lanes 32-63) on both operands.  No LDS: the f32 MFMA takes 64 cycles per SIMD, which
 // leaves the load path far from saturated.
+#include <cstdlib>
+
 #include "common.h"
 #include "../../include/mgx.h"
 
 bool mgx_tconv_applicable(const mgx_conv_desc& d);
+bool mgx_wconv_applicable(const mgx_conv_desc& d);
+int mgx_wconv_launch(const mgx_conv_desc& d, const float* x, const float* w, const float* bias, float* y, float* dact,
+                     hipStream_t st);
 int mgx_tconv_launch(const mgx_conv_desc& d, const float* x, const float* xmul, const float* w, const float* bias,
                      float* y, float* dact, hipStream_t st);
 
@@ -298,6 +303,15 @@ int launch_pointwise2(const mgx_conv_desc& d, const float* x, const float* w, co
 
 bool mgx_pointwise2_applicable(const mgx_conv_desc& d) { return pointwise2_applicable(d, nullptr); }
 
+// The Winograd forward kernel is used unless the environment says MGX_WINOGRAD=0 (read once).
+bool mgx_wconv_enabled() {
+    static const bool on = [] {
+        const char* e = getenv("MGX_WINOGRAD");
+        return !(e && e[0] == '0');
+    }();
+    return on;
+}
+
 extern "C" int mgx_conv_gemm_f32(const mgx_conv_desc* dp, const float* x, const float* xmul, const float* w,
                                  const float* bias, float* y, float* dact, void* stream) {
     if (!dp || !x || !w || !y) return MGX_ERR_ARG;
@@ -310,6 +324,7 @@ extern "C" int mgx_conv_gemm_f32(const mgx_conv_desc* dp, const float* x, const 
     // the last gather position of every row grid must be reachable by construction of the layer:
     // out-of-range positions are treated as zero padding, never dereferenced.
     hipStream_t st = (hipStream_t)stream;
+    if (!xmul && mgx_wconv_enabled() && mgx_wconv_applicable(d)) return mgx_wconv_launch(d, x, w, bias, y, dact, st);
     if (mgx_tconv_applicable(d)) return mgx_tconv_launch(d, x, xmul, w, bias, y, dact, st);
     if (pointwise2_applicable(d, xmul)) return launch_pointwise2(d, x, w, bias, y, dact, st);
     const int ntiles = (d.ngemm + 31) / 32;
