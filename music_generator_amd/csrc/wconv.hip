@@ -27,11 +27,14 @@ constexpr int W_NPIX = WIH * WIW;                    // 612
 constexpr int W_U_FLOATS = 16 * 1024;
 constexpr int W_LDS_BYTES = (W_U_FLOATS + W_NPIX * WPS) * 4;      // 153 664
 constexpr int W_SITER = (W_NPIX * 8 + 255) / 256;    // float4 staging loads per thread: 20
+#ifndef W_LOADB
+#define W_LOADB 12
+#endif
 
 // column of the input tile -> position slot of its row (even columns first)
 __host__ __device__ constexpr int wslot(int c) { return (c & 1) * 17 + (c >> 1); }
 
-template <bool DACT>
+template <bool DACT, int S>
 __global__ __launch_bounds__(256, 1) void wino3_kernel(mgx_conv_desc d, const float* __restrict__ x,
                                                        const float* __restrict__ w,
                                                        const float* __restrict__ bias, float* __restrict__ y,
@@ -44,17 +47,20 @@ __global__ __launch_bounds__(256, 1) void wino3_kernel(mgx_conv_desc d, const fl
     const int lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 31, h = lane >> 5;
     const int H = d.hin, W = d.win;
-    const int S = d.cin / 32;             // channel slices = accumulation steps per tile
+    // S = cin / 32 channel slices = accumulation steps per tile (unrolled: the 16 accumulator tiles
+    // must not be carried around a rolled loop)
 
     // ---- transformed filter of slice kc: thread (kq, n) owns 4 input channels x 1 output channel ----
     auto u_fill = [&](int kc) {
-        const int kq = tid >> 5, n = tid & 31;
+        int tq = tid;
+        asm volatile("" : "+v"(tq));       // keeps the 36 load addresses from being hoisted out of the tile loop
+        const int kq = tq >> 5, n = tq & 31;
+        const float* wp = w + (long)(kc * 32 + kq * 4) * d.wsk + n;
         float g[9][4];
 #pragma unroll
         for (int tap = 0; tap < 9; ++tap)
 #pragma unroll
-            for (int j = 0; j < 4; ++j)
-                g[tap][j] = w[(long)tap * d.wtap + (long)(kc * 32 + kq * 4 + j) * d.wsk + n];
+            for (int j = 0; j < 4; ++j) g[tap][j] = wp[(long)tap * d.wtap + (long)j * d.wsk];
         f32x4 u[16];
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
@@ -156,46 +162,70 @@ __global__ __launch_bounds__(256, 1) void wino3_kernel(mgx_conv_desc d, const fl
         for (int p = 0; p < 16; ++p)
 #pragma unroll
             for (int i = 0; i < 16; ++i) acc[p][i] = 0.f;
+#pragma unroll
         for (int kc = 0; kc < S; ++kc) {
         const int kcn = kc + 1 == S ? 0 : kc + 1;
         const long tn = kc + 1 == S ? t + gridDim.x : t;
         const bool has_next = tn < ntiles;
-        // ---- 16 blocks (4 channel quads x 4 row combinations) of 16 MFMAs; the 12 LDS reads of
-        //      block b+1 are issued before the MFMAs of block b.  The loads of the next tile start
-        //      before the last quad: early enough to hide most of their latency, late enough that
-        //      their 80 registers do not compete with the read-ahead of the first three quads.
+        // ---- 16 blocks (4 channel quads x 4 row combinations) of 16 MFMAs, software-pipelined: while
+        //      block b multiplies, the fragment of block b+1 is transformed in four slices of 8
+        //      vector instructions (one after every 4 MFMAs), the 8 LDS reads of block b+2 go out as
+        //      soon as the row combinations of b+1 have consumed their registers, and the filter
+        //      fragment of block b+2 is read when the last MFMA of block b has been issued.
         {
             constexpr int RA[4] = {0, 1, 2, 1}, RB[4] = {2, 2, 1, 3};      // rows of row combination xi
             constexpr float SG[4] = {-1.f, 1.f, -1.f, -1.f};               // sign of the second row
-            f32x4 da[2][4], db[2][4], uu[2][4];
-            auto rd = [&](int b, int slot) {
+            f32x4 da[4], db[4], uu[2][4], V[2][4], T[4];
+            auto rd = [&](int b) {
                 const int jq = b >> 2, xi = b & 3;
 #pragma unroll
                 for (int c = 0; c < 4; ++c) {
                     const int so = ((c & 1) * 17 + (c >> 1)) * WPS + 4 * jq;
-                    da[slot][c] = *(const f32x4*)(abase + RA[xi] * WIW * WPS + so);
-                    db[slot][c] = *(const f32x4*)(abase + RB[xi] * WIW * WPS + so);
-                    uu[slot][c] = *(const f32x4*)(ubase + (xi * 4 + c) * 1024 + jq * 128);
+                    da[c] = *(const f32x4*)(abase + RA[xi] * WIW * WPS + so);
+                    db[c] = *(const f32x4*)(abase + RB[xi] * WIW * WPS + so);
                 }
             };
-            rd(0, 0);
+            auto ru = [&](int b, int slot) {
+#pragma unroll
+                for (int c = 0; c < 4; ++c)
+                    uu[slot][c] = *(const f32x4*)(ubase + ((b & 3) * 4 + c) * 1024 + (b >> 2) * 128);
+            };
+            auto rows = [&](int b, int c0) {                               // row combination of columns c0, c0+1
+                T[c0] = da[c0] + SG[b & 3] * db[c0];
+                T[c0 + 1] = da[c0 + 1] + SG[b & 3] * db[c0 + 1];
+            };
+            auto mm = [&](int b, int s) {
+                const int xi = b & 3, cs = b & 1;
+#pragma unroll
+                for (int c = 0; c < 4; ++c) acc[xi * 4 + c] = mfma32(V[cs][c][s], uu[cs][c][s], acc[xi * 4 + c]);
+            };
+            rd(0);
+            ru(0, 0);
+            rows(0, 0);
+            rows(0, 2);
+            V[0][0] = T[0] - T[2], V[0][1] = T[1] + T[2], V[0][2] = T[2] - T[1], V[0][3] = T[1] - T[3];
+            rd(1);
+            ru(1, 1);
+            __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
             for (int b = 0; b < 16; ++b) {
-                const int xi = b & 3, cs = b & 1;
-                if (b == 12 && has_next) stage_load(tn, kcn);
-                if (b + 1 < 16) rd(b + 1, cs ^ 1);
-                f32x4 T[4];
-#pragma unroll
-                for (int c = 0; c < 4; ++c) T[c] = da[cs][c] + SG[xi] * db[cs][c];
-                const f32x4 V0 = T[0] - T[2], V1 = T[1] + T[2], V2 = T[2] - T[1], V3 = T[1] - T[3];
-#pragma unroll
-                for (int s = 0; s < 4; ++s) {
-                    acc[xi * 4 + 0] = mfma32(V0[s], uu[cs][0][s], acc[xi * 4 + 0]);
-                    acc[xi * 4 + 1] = mfma32(V1[s], uu[cs][1][s], acc[xi * 4 + 1]);
-                    acc[xi * 4 + 2] = mfma32(V2[s], uu[cs][2][s], acc[xi * 4 + 2]);
-                    acc[xi * 4 + 3] = mfma32(V3[s], uu[cs][3][s], acc[xi * 4 + 3]);
-                }
+                const int cn = (b & 1) ^ 1;
+                const bool more = b + 1 < 16, more2 = b + 2 < 16;
+                if (b == W_LOADB && has_next) stage_load(tn, kcn);
+                mm(b, 0);
+                if (more) rows(b + 1, 0);
                 __builtin_amdgcn_sched_barrier(0);
+                mm(b, 1);
+                if (more) rows(b + 1, 2);
+                __builtin_amdgcn_sched_barrier(0);
+                if (more2) rd(b + 2);
+                mm(b, 2);
+                if (more) V[cn][0] = T[0] - T[2], V[cn][1] = T[1] + T[2];
+                __builtin_amdgcn_sched_barrier(0);
+                mm(b, 3);
+                if (more) V[cn][2] = T[2] - T[1], V[cn][3] = T[1] - T[3];
+                __builtin_amdgcn_sched_barrier(0);
+                if (more2) ru(b + 2, b & 1);
             }
         }
         __syncthreads();                                   // every wave is done with the tile and with U
@@ -289,19 +319,20 @@ int mgx_wconv_launch(const mgx_conv_desc& d, const float* x, const float* w, con
     const int tiles_h = (d.hin + WTH - 1) / WTH, tiles_w = (d.win + WTW - 1) / WTW;
     const long ntiles = (long)d.nimg * tiles_h * tiles_w;
     const unsigned grid = (unsigned)(ntiles < 256 ? ntiles : 256);
-#define MGX_W3(DD)                                                                                                  \
+#define MGX_W3(DD, SS)                                                                                              \
     do {                                                                                                            \
         static bool allowed = false;                                                                                \
         if (!allowed) {                                                                                             \
-            (void)hipFuncSetAttribute((const void*)wino3_kernel<DD>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+            (void)hipFuncSetAttribute((const void*)wino3_kernel<DD, SS>, hipFuncAttributeMaxDynamicSharedMemorySize, \
                                       W_LDS_BYTES);                                                                 \
             allowed = true;                                                                                         \
         }                                                                                                           \
-        hipLaunchKernelGGL((wino3_kernel<DD>), dim3(grid), dim3(256), W_LDS_BYTES, st, d, x, w, bias, y, dact,   \
+        hipLaunchKernelGGL((wino3_kernel<DD, SS>), dim3(grid), dim3(256), W_LDS_BYTES, st, d, x, w, bias, y, dact,   \
                            ntiles, tiles_h, tiles_w);                                                               \
     } while (0)
-    if (dact) MGX_W3(true);
-    else MGX_W3(false);
+    const int S = d.cin / 32;
+    if (dact) { if (S == 2) MGX_W3(true, 2); else if (S == 3) MGX_W3(true, 3); else MGX_W3(true, 4); }
+    else { if (S == 2) MGX_W3(false, 2); else if (S == 3) MGX_W3(false, 3); else MGX_W3(false, 4); }
 #undef MGX_W3
     return mgx_launch_status();
 }
