@@ -6,310 +6,442 @@
 //
 // A workgroup of 4 waves (one per SIMD, 16 accumulator tiles each) owns a tile of 16 output rows x
 // 32 columns; wave w owns rows 4w..4w+3 = 2 x 16 patches, which are the 32 rows of its MFMA tiles.
-// For each of the 16 transform positions (xi, nu) the patch-by-channel matrix V[xi,nu] (32 x 32)
-// times the transformed filter U[xi,nu] (32 x 32) accumulates into M[xi,nu]; input channels beyond
-// 32 are further accumulation steps in the transform domain.  LDS holds U of the current channel
-// slice ([xi nu][k/4][n][4], 64 KiB) and ONE input tile with halo (18 x 34 positions x 32
-// channels, 36-float stride, even and odd columns stored apart so that the stride-2 patch reads of
-// 16 lanes touch consecutive positions).  V is never stored: a lane builds its fragment from 8
-// 16-byte LDS reads per 4 positions (the row combination first, then the 4 column combinations),
-// the vector work sits between the MFMAs of 16 independent accumulators.  The next tile travels
-// through registers while the current one is computed.  Epilogue: output transform in registers
-// (an accumulator register of the 16 tiles is one patch x output channel), bias, tanh(x)+x/alpha,
-// optional derivative store.
+// For each of the 16 transform positions (xi, nu) the patch-by-channel matrix V[xi,nu] (32 x k)
+// times the transformed filter U[xi,nu] (k x 32) accumulates into M[xi,nu].  The input channels are
+// consumed in slices of 16: one accumulation step = 8 blocks of 16 MFMAs.
+//
+// On this chip every vector-ALU instruction takes issue cycles away from the fp32 MFMAs of its
+// SIMD, so the kernel is built to execute as few of them as possible:
+//  * the input tile of the NEXT step (18 x 34 positions x 16 channels) travels global -> LDS by
+//    buffer loads with the LDS destination (no registers, no LDS store instructions, zero fill of
+//    the halo outside the image by the buffer range check) while the current step multiplies; two
+//    tile buffers alternate.  A position is 64 bytes; its four 16-byte channel quads are stored
+//    XOR-swizzled with bits 2..3 of the position slot, the even and odd columns of a row apart, so
+//    that the stride-2 patch reads of a 16-lane group cover all 64 banks;
+//  * V is never stored: a lane builds its fragment from 8 16-byte LDS reads per 4 channels with 16
+//    packed (two floats per lane) additions, slotted between the MFMAs of the previous block;
+//  * all addresses of the main loop are per-lane constants plus immediates or scalars.
+// U of a 32-channel convolution stays in LDS for the whole kernel; wider inputs stream it one
+// slice ahead (36 dword loads and 35 packed operations per thread and step).  Epilogue: output
+// transform on register pairs (an accumulator register of the 16 tiles is one patch x output
+// channel), bias, tanh(x)+x/alpha, optional derivative store.
 #include "common.h"
 #include "../../include/mgx.h"
 
 namespace {
 
-constexpr int WTH = 16, WTW = 32, WIH = 18, WIW = 34, WPS = 36;
-constexpr int W_NPIX = WIH * WIW;                    // 612
-constexpr int W_U_FLOATS = 16 * 1024;
-constexpr int W_LDS_BYTES = (W_U_FLOATS + W_NPIX * WPS) * 4;      // 153 664
-constexpr int W_SITER = (W_NPIX * 8 + 255) / 256;    // float4 staging loads per thread: 20
-#ifndef W_LOADB
-#define W_LOADB 12
-#endif
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+typedef __attribute__((address_space(3))) void* lds_ptr_t;
+
+constexpr int WTH = 16, WTW = 32, WIH = 18;
+constexpr int W_RS = 40;                              // position slots per tile row (34 used)
+constexpr int W_TILE = WIH * W_RS * 16;               // floats per tile buffer (16 channels per slot)
+constexpr int W_USLICE = 16 * 4 * 128;                // floats of U per 16-channel slice: [xi nu][k/4][n][4]
+constexpr int W_LDS_BYTES = (2 * W_USLICE + 2 * W_TILE) * 4;      // 157 696
+
+__device__ __forceinline__ f32x2 pk_add(f32x2 a, f32x2 b) {
+    f32x2 r;
+    asm("v_pk_add_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ f32x2 pk_sub(f32x2 a, f32x2 b) {
+    f32x2 r;
+    asm("v_pk_add_f32 %0, %1, %2 neg_lo:[0,1] neg_hi:[0,1]" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ f32x2 pk_mul(f32x2 a, f32x2 b) {
+    f32x2 r;
+    asm("v_pk_mul_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
+    return r;
+}
+__device__ __forceinline__ f32x2 pk_fma(f32x2 a, f32x2 b, f32x2 c) {
+    f32x2 r;
+    asm("v_pk_fma_f32 %0, %1, %2, %3" : "=v"(r) : "v"(a), "v"(b), "v"(c));
+    return r;
+}
+// The result of a transcendental instruction (v_exp_f32, v_rcp_f32) needs a wait state before an
+// ordinary vector instruction may read it.  The compiler inserts it for the instructions it
+// selects itself, not for the operands of an asm statement: values that go from a transcendental
+// into one of the packed helpers above pass through this first.
+__device__ __forceinline__ void trans_settle(f32x2& v) { asm volatile("s_nop 1" : "+v"(v)); }
+__device__ __forceinline__ f32x2 pair16(f32x16 v, int k) { return f32x2{v[2 * k], v[2 * k + 1]}; }
+__device__ __forceinline__ f32x16 add16(f32x16 a, f32x16 b) {
+    f32x16 r;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const f32x2 t = pk_add(pair16(a, k), pair16(b, k));
+        r[2 * k] = t[0], r[2 * k + 1] = t[1];
+    }
+    return r;
+}
+__device__ __forceinline__ f32x16 sub16(f32x16 a, f32x16 b) {
+    f32x16 r;
+#pragma unroll
+    for (int k = 0; k < 8; ++k) {
+        const f32x2 t = pk_sub(pair16(a, k), pair16(b, k));
+        r[2 * k] = t[0], r[2 * k + 1] = t[1];
+    }
+    return r;
+}
+__device__ __forceinline__ f32x2 lo2(f32x4 v) { return __builtin_shufflevector(v, v, 0, 1); }
+__device__ __forceinline__ f32x2 hi2(f32x4 v) { return __builtin_shufflevector(v, v, 2, 3); }
 
 // column of the input tile -> position slot of its row (even columns first)
 __host__ __device__ constexpr int wslot(int c) { return (c & 1) * 17 + (c >> 1); }
 
-template <bool DACT, int S>
+struct WTile {
+    int img, th, tw;
+};
+
+// MODE 0: linear output, 1: tanh(x)+x/alpha, 2: the same and the derivative stored to dact.
+// S16 = cin / 16 accumulation steps per tile (unrolled: the 16 accumulator tiles must not be
+// carried around a rolled loop; S16 is even, so the buffer of a step is a compile-time constant).
+template <int MODE, int S16>
 __global__ __launch_bounds__(256, 1) void wino3_kernel(mgx_conv_desc d, const float* __restrict__ x,
                                                        const float* __restrict__ w,
                                                        const float* __restrict__ bias, float* __restrict__ y,
                                                        float* __restrict__ dact, long ntiles, int tiles_h,
                                                        int tiles_w) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    float* ul = lds;                      // [16][8][32][4]
-    float* xt = lds + W_U_FLOATS;         // [WIH][34 slots][36]
+    float* ul = lds;                      // [2][16][4][32][4]
+    float* xt = lds + 2 * W_USLICE;       // [2][WIH][W_RS][16]
+    constexpr bool kResidentU = S16 == 2;
     const int tid = threadIdx.x;
     const int lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 31, h = lane >> 5;
-    const int H = d.hin, W = d.win;
-    // S = cin / 32 channel slices = accumulation steps per tile (unrolled: the 16 accumulator tiles
-    // must not be carried around a rolled loop)
+    const int H = d.hin, W = d.win, cin = d.cin;
 
-    // ---- transformed filter of slice kc: thread (kq, n) owns 4 input channels x 1 output channel ----
-    auto u_fill = [&](int kc) {
-        int tq = tid;
-        asm volatile("" : "+v"(tq));       // keeps the 36 load addresses from being hoisted out of the tile loop
-        const int kq = tq >> 5, n = tq & 31;
-        const float* wp = w + (long)(kc * 32 + kq * 4) * d.wsk + n;
-        float g[9][4];
+    // ---- transformed filter of a 16-channel slice: thread (kq, n, half) owns 2 input channels x 1
+    //      output channel; the 18 addresses are one per-thread offset plus a scalar ----
+    const __amdgpu_buffer_rsrc_t rw =
+        __builtin_amdgcn_make_buffer_rsrc((void*)w, 0, (unsigned)(9 * cin * 32 * 4), 0x00020000);
+    const int ukq = tid >> 6, un = (tid >> 1) & 31, uhalf = tid & 1;
+    const unsigned uvoff = (unsigned)(((ukq * 4 + 2 * uhalf) * 32 + un) * 4);
+    float* const ustore = ul + ukq * 128 + un * 4 + 2 * uhalf;
+    auto u_load = [&](int slice, f32x2 (&g)[9]) {
 #pragma unroll
-        for (int tap = 0; tap < 9; ++tap)
-#pragma unroll
-            for (int j = 0; j < 4; ++j) g[tap][j] = wp[(long)tap * d.wtap + (long)j * d.wsk];
-        f32x4 u[16];
-#pragma unroll
-        for (int j = 0; j < 4; ++j) {
-            float gg[4][3];               // G g: rows xi
-#pragma unroll
-            for (int b = 0; b < 3; ++b) {
-                const float g0 = g[b][j], g1 = g[3 + b][j], g2 = g[6 + b][j];
-                gg[0][b] = g0;
-                gg[1][b] = 0.5f * (g0 + g1 + g2);
-                gg[2][b] = 0.5f * (g0 - g1 + g2);
-                gg[3][b] = g2;
-            }
-#pragma unroll
-            for (int xi = 0; xi < 4; ++xi) {
-                const float a0 = gg[xi][0], a1 = gg[xi][1], a2 = gg[xi][2];
-                u[xi * 4 + 0][j] = a0;
-                u[xi * 4 + 1][j] = 0.5f * (a0 + a1 + a2);
-                u[xi * 4 + 2][j] = 0.5f * (a0 - a1 + a2);
-                u[xi * 4 + 3][j] = a2;
-            }
+        for (int tap = 0; tap < 9; ++tap) {
+            const int soff = ((tap * cin + slice * 16) * 32) * 4;
+            g[tap][0] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rw, uvoff, soff, 0));
+            g[tap][1] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rw, uvoff + 128, soff, 0));
         }
+    };
+    auto u_store = [&](int ubuf, const f32x2 (&g)[9]) {
+        const f32x2 half2 = {0.5f, 0.5f};
+        f32x2 gg[4][3];                    // G g: rows xi
 #pragma unroll
-        for (int p = 0; p < 16; ++p) *(f32x4*)(ul + (p * 8 + kq) * 128 + n * 4) = u[p];
+        for (int b = 0; b < 3; ++b) {
+            const f32x2 t = pk_add(g[b], g[6 + b]);
+            gg[0][b] = g[b];
+            gg[1][b] = pk_mul(pk_add(t, g[3 + b]), half2);
+            gg[2][b] = pk_mul(pk_sub(t, g[3 + b]), half2);
+            gg[3][b] = g[6 + b];
+        }
+        float* up = ustore + ubuf * W_USLICE;
+#pragma unroll
+        for (int xi = 0; xi < 4; ++xi) {
+            const f32x2 t = pk_add(gg[xi][0], gg[xi][2]);
+            *(f32x2*)(up + (xi * 4 + 0) * 512) = gg[xi][0];
+            *(f32x2*)(up + (xi * 4 + 1) * 512) = pk_mul(pk_add(t, gg[xi][1]), half2);
+            *(f32x2*)(up + (xi * 4 + 2) * 512) = pk_mul(pk_sub(t, gg[xi][1]), half2);
+            *(f32x2*)(up + (xi * 4 + 3) * 512) = gg[xi][2];
+        }
     };
 
-    // ---- input tile staging through registers; out-of-image positions read as zeros ----
-    auto tile_of = [&](long t, long& img, int& h0, int& w0) {
+    // ---- tile walk in scalar registers: (image, tile row, tile column) advance by the grid size ----
+    WTile dstep, cur;
+    {
         const unsigned per_img = (unsigned)(tiles_h * tiles_w);
-        const unsigned tu = (unsigned)t;
-        const unsigned im = tu / per_img;
-        const unsigned rem = tu - im * per_img;
-        const unsigned th = rem / (unsigned)tiles_w;
-        img = im;
-        h0 = (int)th * WTH;
-        w0 = (int)(rem - th * tiles_w) * WTW;
+        const unsigned g = gridDim.x, b = blockIdx.x;
+        dstep.img = (int)(g / per_img);
+        unsigned rem = g - (unsigned)dstep.img * per_img;
+        dstep.th = (int)(rem / (unsigned)tiles_w);
+        dstep.tw = (int)(rem - (unsigned)dstep.th * tiles_w);
+        cur.img = (int)(b / per_img);
+        rem = b - (unsigned)cur.img * per_img;
+        cur.th = (int)(rem / (unsigned)tiles_w);
+        cur.tw = (int)(rem - (unsigned)cur.th * tiles_w);
+    }
+    auto advance = [&](WTile t) {
+        t.tw += dstep.tw;
+        if (t.tw >= tiles_w) t.tw -= tiles_w, ++t.th;
+        t.th += dstep.th;
+        if (t.th >= tiles_h) t.th -= tiles_h, ++t.img;
+        t.img += dstep.img;
+        return t;
     };
-    const int c4 = tid & 7;
-    const unsigned band_bytes = (unsigned)WIH * W * d.cin * 4u;
-    f32x4 sv[W_SITER];
-    // The 20 (row, column) pairs of a thread are re-derived at every call from one opaque register:
-    // left to itself the compiler hoists 60 loop-invariant offsets out of the tile loop and
-    // spills them.
-    auto stage_load = [&](long t, int kc) {
-        long img; int h0, w0;
-        tile_of(t, img, h0, w0);
-        const int hb = h0 - 1, wb = w0 - 1;
-        const long band = ((img * H + hb) * (long)W) * d.cin;
-        const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)(x + band), 0, band_bytes, 0x00020000);
-        int p0 = tid >> 3;
-        asm volatile("" : "+v"(p0));
-        int ty = 0, tx = p0;                               // p0 < 32 < WIW
-        const int cbase = (wb * d.cin + kc * 32 + c4 * 4) * 4;
+
+    // ---- input tile global -> LDS.  Wave w moves tile rows w, w+4, ...; a row is three
+    //      instructions of 16 position slots (the third half-masked).  Lane l of an instruction
+    //      writes chunk l&3 of slot l>>2 and therefore fetches channel quad (l&3) ^ (slot>>2 & 3)
+    //      of the column that slot stands for. ----
+    int dcol[3];
+    unsigned dbase[3];
 #pragma unroll
-        for (int i = 0; i < W_SITER; ++i) {
-            const unsigned hi = (unsigned)(ty + hb), wi = (unsigned)(tx + wb);
-            const bool ok = ty < WIH && hi < (unsigned)H && wi < (unsigned)W;
-            const unsigned off = ok ? (unsigned)((ty * W + tx) * d.cin * 4 + cbase) : 0x80000000u;
-            sv[i] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, off, 0, 0));
-            tx += 32;
-            const int wrap = tx >= WIW ? 1 : 0;
-            tx -= wrap * WIW;
-            ty += wrap;
-        }
-    };
-    auto stage_write = [&]() {
-        int p0 = tid >> 3;
-        asm volatile("" : "+v"(p0));
-        int ty = 0, tx = p0;
+    for (int k = 0; k < 3; ++k) {
+        const int sl = 16 * k + (lane >> 2);
+        const int c = sl < 17 ? 2 * sl : 2 * (sl - 17) + 1;
+        const int q = (lane & 3) ^ ((sl >> 2) & 3);
+        dcol[k] = sl < 34 ? c : -0x40000000;           // unused slots: never inside the image
+        dbase[k] = (unsigned)((c * cin + q * 4) * 4);
+    }
+    const unsigned band_bytes = (unsigned)WIH * W * cin * 4u;
+    const int row_bytes_in = W * cin * 4;
+    auto dma_issue = [&](WTile t, int k16, int buf) {
+        const int hb = t.th * WTH - 1, wb = t.tw * WTW - 1;
+        const float* origin = x + (((long)t.img * H + hb) * (long)W + wb) * cin + k16 * 16;
+        const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)origin, 0, band_bytes, 0x00020000);
+        const __amdgpu_buffer_rsrc_t rz = __builtin_amdgcn_make_buffer_rsrc((void*)origin, 0, 0, 0x00020000);
+        unsigned vo[3];
 #pragma unroll
-        for (int i = 0; i < W_SITER; ++i) {
-            if (ty < WIH) *(f32x4*)(xt + (ty * WIW + (tx & 1) * 17 + (tx >> 1)) * WPS + c4 * 4) = sv[i];
-            tx += 32;
-            const int wrap = tx >= WIW ? 1 : 0;
-            tx -= wrap * WIW;
-            ty += wrap;
+        for (int k = 0; k < 3; ++k) vo[k] = (unsigned)(dcol[k] + wb) < (unsigned)W ? dbase[k] : 0x80000000u;
+#pragma unroll
+        for (int i = 0; i < 5; ++i) {
+            const int row = wv + 4 * i;
+            if (row < WIH) {
+                const bool row_ok = (unsigned)(hb + row) < (unsigned)H;
+                const __amdgpu_buffer_rsrc_t rs = row_ok ? rx : rz;
+                const int soff = row * row_bytes_in;
+                float* dst = xt + buf * W_TILE + row * (W_RS * 16);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr_t)dst, 16, vo[0], soff, 0, 0);
+                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr_t)(dst + 256), 16, vo[1], soff, 0, 0);
+                if (lane < 32) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr_t)(dst + 512), 16, vo[2], soff, 0, 0);
+            }
         }
     };
 
     // ---- per-lane constants of the MFMA phase ----
     const int tr = r >> 4, tc = r & 15;
-    const float* abase = xt + ((4 * wv + 2 * tr) * WIW + tc) * WPS + 16 * h;
-    const float* ubase = ul + (4 * h) * 128 + r * 4;
+    const float* aptr[2][4];              // [channel block jb][patch column c]
+#pragma unroll
+    for (int c = 0; c < 4; ++c) {
+        const int sl = wslot(c) + tc;
+#pragma unroll
+        for (int jb = 0; jb < 2; ++jb)
+            aptr[jb][c] = xt + ((4 * wv + 2 * tr) * W_RS + sl) * 16 + (((2 * jb + h) ^ ((sl >> 2) & 3)) * 4);
+    }
+    const float* ubase = ul + h * 128 + r * 4;
     const float inv_alpha = d.act_alpha > 0.f ? 1.0f / d.act_alpha : 0.f;
-    const unsigned row_bytes = (unsigned)W * d.ngemm * 4u;
+    const unsigned out_row_bytes = (unsigned)W * 32u * 4u;
 
     long t = blockIdx.x;
-    u_fill(0);
-    if (t < ntiles) {
-        stage_load(t, 0);
-        stage_write();
+    {
+        f32x2 g[9];
+        u_load(0, g);
+        if (t < ntiles) dma_issue(cur, 0, 0);
+        u_store(0, g);
+        if (kResidentU) {
+            u_load(1, g);
+            u_store(1, g);
+        }
     }
-    __syncthreads();
-    // The accumulators are defined inside one tile iteration and only ever written by MFMAs inside
-    // the step loop: a conditional reset carried around the tile loop makes them pass through 256
-    // vector registers at the back edge.
+    asm volatile("s_waitcnt vmcnt(0) lgkmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    asm volatile("" ::: "memory");
+
     while (t < ntiles) {
+        const WTile nxt = advance(cur);
+        const bool next_tile = t + gridDim.x < ntiles;
         f32x16 acc[16];
 #pragma unroll
         for (int p = 0; p < 16; ++p)
 #pragma unroll
             for (int i = 0; i < 16; ++i) acc[p][i] = 0.f;
 #pragma unroll
-        for (int kc = 0; kc < S; ++kc) {
-        const int kcn = kc + 1 == S ? 0 : kc + 1;
-        const long tn = kc + 1 == S ? t + gridDim.x : t;
-        const bool has_next = tn < ntiles;
-        // ---- 16 blocks (4 channel quads x 4 row combinations) of 16 MFMAs, software-pipelined: while
-        //      block b multiplies, the fragment of block b+1 is transformed in four slices of 8
-        //      vector instructions (one after every 4 MFMAs), the 8 LDS reads of block b+2 go out as
-        //      soon as the row combinations of b+1 have consumed their registers, and the filter
-        //      fragment of block b+2 is read when the last MFMA of block b has been issued.
-        {
-            constexpr int RA[4] = {0, 1, 2, 1}, RB[4] = {2, 2, 1, 3};      // rows of row combination xi
-            constexpr float SG[4] = {-1.f, 1.f, -1.f, -1.f};               // sign of the second row
-            f32x4 da[4], db[4], uu[2][4], V[2][4], T[4];
-            auto rd = [&](int b) {
-                const int jq = b >> 2, xi = b & 3;
+        for (int k16 = 0; k16 < S16; ++k16) {
+            constexpr int kDummy = 0;
+            (void)kDummy;
+            const int buf = k16 & 1, ubuf = k16 & 1;
+            const bool last = k16 + 1 == S16;
+            const int kn = last ? 0 : k16 + 1;
+            // the tile and filter slice of the next step go into the buffers the previous step used
+            if (!last || next_tile) dma_issue(last ? nxt : cur, kn, buf ^ 1);
+            f32x2 g[9];
+            if (!kResidentU) u_load(kn, g);
+            // ---- 8 blocks (2 channel blocks x 4 row combinations) of 16 MFMAs, software-pipelined:
+            //      while block b multiplies, the fragment of block b+1 is transformed in four slices
+            //      of 4 packed instructions (one after every 4 MFMAs), the 8 LDS reads of block b+2
+            //      go out as soon as the row combinations of b+1 have consumed their registers, and
+            //      the filter fragment of block b+2 is read when the last MFMA of block b is issued.
+            {
+                constexpr int RA[4] = {0, 1, 2, 1}, RB[4] = {2, 2, 1, 3};      // rows of row combination xi
+                constexpr bool PLUS[4] = {false, true, false, false};         // sign of the second row
+                f32x4 da[4], db[4], uu[2][4];
+                f32x2 V[2][4][2], T[4][2];
+                auto rd = [&](int b) {
+                    const int jb = b >> 2, xi = b & 3;
 #pragma unroll
-                for (int c = 0; c < 4; ++c) {
-                    const int so = ((c & 1) * 17 + (c >> 1)) * WPS + 4 * jq;
-                    da[c] = *(const f32x4*)(abase + RA[xi] * WIW * WPS + so);
-                    db[c] = *(const f32x4*)(abase + RB[xi] * WIW * WPS + so);
-                }
-            };
-            auto ru = [&](int b, int slot) {
-#pragma unroll
-                for (int c = 0; c < 4; ++c)
-                    uu[slot][c] = *(const f32x4*)(ubase + ((b & 3) * 4 + c) * 1024 + (b >> 2) * 128);
-            };
-            auto rows = [&](int b, int c0) {                               // row combination of columns c0, c0+1
-                T[c0] = da[c0] + SG[b & 3] * db[c0];
-                T[c0 + 1] = da[c0 + 1] + SG[b & 3] * db[c0 + 1];
-            };
-            auto mm = [&](int b, int s) {
-                const int xi = b & 3, cs = b & 1;
-#pragma unroll
-                for (int c = 0; c < 4; ++c) acc[xi * 4 + c] = mfma32(V[cs][c][s], uu[cs][c][s], acc[xi * 4 + c]);
-            };
-            rd(0);
-            ru(0, 0);
-            rows(0, 0);
-            rows(0, 2);
-            V[0][0] = T[0] - T[2], V[0][1] = T[1] + T[2], V[0][2] = T[2] - T[1], V[0][3] = T[1] - T[3];
-            rd(1);
-            ru(1, 1);
-            __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-            for (int b = 0; b < 16; ++b) {
-                const int cn = (b & 1) ^ 1;
-                const bool more = b + 1 < 16, more2 = b + 2 < 16;
-                if (b == W_LOADB && has_next) stage_load(tn, kcn);
-                mm(b, 0);
-                if (more) rows(b + 1, 0);
-                __builtin_amdgcn_sched_barrier(0);
-                mm(b, 1);
-                if (more) rows(b + 1, 2);
-                __builtin_amdgcn_sched_barrier(0);
-                if (more2) rd(b + 2);
-                mm(b, 2);
-                if (more) V[cn][0] = T[0] - T[2], V[cn][1] = T[1] + T[2];
-                __builtin_amdgcn_sched_barrier(0);
-                mm(b, 3);
-                if (more) V[cn][2] = T[2] - T[1], V[cn][3] = T[1] - T[3];
-                __builtin_amdgcn_sched_barrier(0);
-                if (more2) ru(b + 2, b & 1);
-            }
-        }
-        __syncthreads();                                   // every wave is done with the tile and with U
-        if (has_next) stage_write();
-        if (has_next && S > 1) u_fill(kcn);
-        if (kc + 1 < S) __syncthreads();
-        }
-        {
-            // ---- epilogue: output transform, bias, activation, stores ----
-            long img; int h0, w0;
-            tile_of(t, img, h0, w0);
-            const int rows_left = H - h0 < WTH ? H - h0 : WTH;
-            if (4 * wv < rows_left) {                      // H is a multiple of 4: a wave is all in or all out
-                const long bandoff = ((img * H + h0) * (long)W) * d.ngemm;
-                const unsigned bytes = (unsigned)rows_left * row_bytes;
-                const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc((void*)(y + bandoff), 0, bytes, 0x00020000);
-                const __amdgpu_buffer_rsrc_t rd =
-                    __builtin_amdgcn_make_buffer_rsrc((void*)((DACT ? dact : y) + bandoff), 0, bytes, 0x00020000);
-                const float bv = d.nbias > 0 ? bias[r] : 0.f;
-                const bool act = d.act_alpha > 0.f;
-                const int colmax = W - w0 - 8 * h;         // columns of this lane half left in the row
-                const unsigned vbase = (unsigned)((8 * h * d.ngemm + r) * 4);
-                const int pstep = d.ngemm * 4;             // bytes per output position
-                // output transform on whole accumulator tiles (register s of all 16 tiles is one
-                // patch x output channel): Z = A^T M per column nu, then Y = Z A; one output row
-                // parity a at a time keeps the live set small
-#pragma unroll
-                for (int a = 0; a < 2; ++a) {
-                    f32x16 Y[2];
-                    {
-                        f32x16 Z[4];
-#pragma unroll
-                        for (int nu = 0; nu < 4; ++nu) {
-                            Z[nu] = a == 0 ? acc[nu] + acc[4 + nu] : acc[4 + nu] - acc[8 + nu];
-                            __builtin_amdgcn_sched_barrier(0);
-                            Z[nu] = a == 0 ? Z[nu] + acc[8 + nu] : Z[nu] - acc[12 + nu];
-                            __builtin_amdgcn_sched_barrier(0);
-                        }
-                        Y[0] = Z[0] + Z[1] + Z[2];
-                        Y[1] = Z[1] - Z[2] - Z[3];
+                    for (int c = 0; c < 4; ++c) {
+                        da[c] = *(const f32x4*)(aptr[jb][c] + buf * W_TILE + RA[xi] * (W_RS * 16));
+                        db[c] = *(const f32x4*)(aptr[jb][c] + buf * W_TILE + RB[xi] * (W_RS * 16));
                     }
-                    __builtin_amdgcn_sched_barrier(0);
+                };
+                auto ru = [&](int b, int slot) {
+                    const int jb = b >> 2, xi = b & 3;
 #pragma unroll
-                    for (int s = 0; s < 16; ++s) {
-                        const int trs = s >> 3;                                     // patch row of register s
-                        const int cu = 2 * ((s & 3) + 8 * ((s >> 2) & 1));           // column of its patch (lane half 0)
+                    for (int c = 0; c < 4; ++c)
+                        uu[slot][c] = *(const f32x4*)(ubase + ubuf * W_USLICE + ((xi * 4 + c) * 4 + 2 * jb) * 128);
+                };
+                auto rows = [&](int b, int c0) {                           // row combination of columns c0, c0+1
 #pragma unroll
-                        for (int b = 0; b < 2; ++b) {
-                            float v = Y[b][s] + bv;
-                            float der = 0.f;
-                            if (act) {
-                                float tt, s2;
-                                tanh_sech2(v, tt, s2);
-                                der = s2 + inv_alpha;
-                                v = tt + v * inv_alpha;
-                            }
-                            const int soff = ((4 * wv + 2 * trs + a) * W + w0 + cu + b) * pstep;
-                            const unsigned voff = (cu + b < colmax) ? vbase : 0x80000000u;
-                            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, v), ry, voff, soff, 0);
-                            if (DACT && act)
-                                __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, der), rd, voff, soff, 0);
+                    for (int c = c0; c < c0 + 2; ++c) {
+                        T[c][0] = PLUS[b & 3] ? pk_add(lo2(da[c]), lo2(db[c])) : pk_sub(lo2(da[c]), lo2(db[c]));
+                        T[c][1] = PLUS[b & 3] ? pk_add(hi2(da[c]), hi2(db[c])) : pk_sub(hi2(da[c]), hi2(db[c]));
+                    }
+                };
+                auto cols = [&](int slot, int half) {                      // column combinations 2*half, 2*half+1
+#pragma unroll
+                    for (int q = 0; q < 2; ++q) {
+                        if (half == 0) {
+                            V[slot][0][q] = pk_sub(T[0][q], T[2][q]);
+                            V[slot][1][q] = pk_add(T[1][q], T[2][q]);
+                        } else {
+                            V[slot][2][q] = pk_sub(T[2][q], T[1][q]);
+                            V[slot][3][q] = pk_sub(T[1][q], T[3][q]);
                         }
+                    }
+                };
+                auto mm = [&](int b, int s) {
+                    const int xi = b & 3, cs = b & 1;
+#pragma unroll
+                    for (int c = 0; c < 4; ++c)
+                        acc[xi * 4 + c] = mfma32(V[cs][c][s >> 1][s & 1], uu[cs][c][s], acc[xi * 4 + c]);
+                };
+                rd(0);
+                ru(0, 0);
+                rows(0, 0);
+                rows(0, 2);
+                cols(0, 0);
+                cols(0, 1);
+                rd(1);
+                ru(1, 1);
+                __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+                for (int b = 0; b < 8; ++b) {
+                    const int cn = (b & 1) ^ 1;
+                    const bool more = b + 1 < 8, more2 = b + 2 < 8;
+                    mm(b, 0);
+                    if (more) rows(b + 1, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                    mm(b, 1);
+                    if (more) rows(b + 1, 2);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (more2) rd(b + 2);
+                    mm(b, 2);
+                    if (more) cols(cn, 0);
+                    __builtin_amdgcn_sched_barrier(0);
+                    mm(b, 3);
+                    if (more) cols(cn, 1);
+                    __builtin_amdgcn_sched_barrier(0);
+                    if (more2) ru(b + 2, b & 1);
+                    if (!kResidentU && b == 5) {
+                        u_store(ubuf ^ 1, g);
                         __builtin_amdgcn_sched_barrier(0);
                     }
                 }
             }
+            // every load into LDS issued by this wave has landed (they were issued a whole step ago)
+            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+            if (last) {
+                // ---- epilogue: output transform, bias, activation, stores.  One buffer resource
+                //      per output row clips the columns beyond the image by its range check. ----
+                const int h0 = cur.th * WTH, w0 = cur.tw * WTW;
+                if (h0 + 4 * wv < H) {                     // H is a multiple of 4: a wave is all in or all out
+                    const unsigned vbase = (unsigned)(((w0 + 8 * h) * 32 + r) * 4);
+                    const float bv = d.nbias > 0 ? bias[r] : 0.f;
+                    const f32x2 bv2 = {bv, bv}, ia2 = {inv_alpha, inv_alpha};
+                    // Output transform on whole accumulator tiles (register s of all 16 tiles is one
+                    // patch x output channel), one transform column nu at a time:
+                    // Z_a = A^T M[:, nu] for both output row parities a, then Y[a][b] += Z_a A[nu][b].
+                    f32x16 Y[2][2];
+#pragma unroll
+                    for (int nu = 0; nu < 4; ++nu) {
+                        const f32x16 m0 = acc[nu], m1 = acc[4 + nu], m2 = acc[8 + nu], m3 = acc[12 + nu];
+                        f32x16 z[2];
+                        z[0] = add16(add16(m0, m1), m2);
+                        z[1] = sub16(sub16(m1, m2), m3);
+#pragma unroll
+                        for (int a = 0; a < 2; ++a) {
+                            if (nu == 0) Y[a][0] = z[a];
+                            if (nu == 1) Y[a][0] = add16(Y[a][0], z[a]), Y[a][1] = z[a];
+                            if (nu == 2) Y[a][0] = add16(Y[a][0], z[a]), Y[a][1] = sub16(Y[a][1], z[a]);
+                            if (nu == 3) Y[a][1] = sub16(Y[a][1], z[a]);
+                        }
+                        __builtin_amdgcn_sched_barrier(0);
+                    }
+#pragma unroll
+                    for (int a = 0; a < 2; ++a) {
+#pragma unroll
+                        for (int trs = 0; trs < 2; ++trs) {                         // patch row of registers 8 trs ..
+                            const long rowoff = (((long)cur.img * H + h0 + 4 * wv + 2 * trs + a) * (long)W) * 32;
+                            const __amdgpu_buffer_rsrc_t ry =
+                                __builtin_amdgcn_make_buffer_rsrc((void*)(y + rowoff), 0, out_row_bytes, 0x00020000);
+                            const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc(
+                                (void*)((MODE == 2 ? dact : y) + rowoff), 0, out_row_bytes, 0x00020000);
+#pragma unroll
+                            for (int b = 0; b < 2; ++b) {
+#pragma unroll
+                                for (int i = 4 * trs; i < 4 * trs + 4; ++i) {       // accumulator registers 2i, 2i+1
+                                    f32x2 v = pk_add(pair16(Y[a][b], i), bv2);
+                                    f32x2 der = {0.f, 0.f};
+                                    if (MODE >= 1) {
+                                        // tanh and sech^2 of both values: e = exp(-2|v|), tanh = sign (1-e)/(1+e),
+                                        // sech^2 = 4e/(1+e)^2 (hardware exp2 and reciprocal, as tanh_sech2)
+                                        const f32x2 c2 = {2.885390081777927f, 2.885390081777927f};
+                                        const f32x2 one = {1.f, 1.f}, four = {4.f, 4.f};
+                                        const f32x2 tt = pk_mul(v, c2);
+                                        f32x2 e;
+                                        e[0] = __builtin_amdgcn_exp2f(-fabsf(tt[0]));
+                                        e[1] = __builtin_amdgcn_exp2f(-fabsf(tt[1]));
+                                        trans_settle(e);
+                                        const f32x2 den = pk_add(one, e);
+                                        f32x2 inv;
+                                        inv[0] = __builtin_amdgcn_rcpf(den[0]);
+                                        inv[1] = __builtin_amdgcn_rcpf(den[1]);
+                                        trans_settle(inv);
+                                        f32x2 mg = pk_mul(pk_sub(one, e), inv);
+                                        mg[0] = copysignf(mg[0], v[0]);
+                                        mg[1] = copysignf(mg[1], v[1]);
+                                        if (MODE == 2) der = pk_fma(pk_mul(pk_mul(four, e), inv), inv, ia2);
+                                        v = pk_fma(v, ia2, mg);
+                                    }
+#pragma unroll
+                                    for (int e2 = 0; e2 < 2; ++e2) {
+                                        const int s = 2 * i + e2;
+                                        const int cu = 2 * ((s & 3) + 8 * ((s >> 2) & 1)) + b;   // column (lane half 0)
+                                        // (a bit_cast applied directly to a vector element reads element 0)
+                                        const float vs = v[e2], ds = der[e2];
+                                        __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, vs), ry,
+                                                                              vbase + cu * 128, 0, 0);
+                                        if (MODE == 2)
+                                            __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, ds), rd,
+                                                                                  vbase + cu * 128, 0, 0);
+                                    }
+                                }
+                                __builtin_amdgcn_sched_barrier(0);
+                            }
+                        }
+                    }
+                }
+            }
+            asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+            __builtin_amdgcn_s_barrier();
+            asm volatile("" ::: "memory");
         }
-        __syncthreads();
         t += gridDim.x;
+        cur = nxt;
     }
 }
 
 }  // namespace
-
 // Forward 3x3 'same' convolutions with 32 output channels that the Winograd kernel covers.
 bool mgx_wconv_applicable(const mgx_conv_desc& d) {
     if (d.kh != 3 || d.kw != 3 || d.sh != 1 || d.sw != 1 || d.dkh != 1 || d.dkw != 1) return false;
     if (d.pt != 1 || d.pl != 1 || d.hout != d.hin || d.wout != d.win || d.flip || d.accumulate) return false;
-    // with a single 32-channel slice the per-tile epilogue outweighs the saved MFMAs: the direct tile
-    // kernel is as fast there
-    if (d.hin % 4 || d.cin % 32 || d.cin < 64 || d.cin > 128 || d.ngemm != 32 || d.cout != 32) return false;
+    if (d.hin % 4 || d.hin < 8 || d.cin % 32 || d.cin < 32 || d.cin > 128 || d.ngemm != 32 || d.cout != 32) return false;
     if (d.wsn != 1 || d.wsk != 32 || d.wtap != (int64_t)d.cin * 32) return false;
     if (d.nbias != 0 && d.nbias != 32) return false;
-    if ((long)WIH * d.win * d.cin * 4 >= (1L << 31) || (long)WTH * d.win * d.ngemm * 4 >= (1L << 31)) return false;
+    if ((long)WIH * d.win * d.cin * 4 >= (1L << 31) || (long)d.win * d.ngemm * 4 >= (1L << 31)) return false;
     const long ntiles = (long)d.nimg * ((d.hin + WTH - 1) / WTH) * ((d.win + WTW - 1) / WTW);
     return ntiles < (1L << 31);
 }
@@ -319,20 +451,30 @@ int mgx_wconv_launch(const mgx_conv_desc& d, const float* x, const float* w, con
     const int tiles_h = (d.hin + WTH - 1) / WTH, tiles_w = (d.win + WTW - 1) / WTW;
     const long ntiles = (long)d.nimg * tiles_h * tiles_w;
     const unsigned grid = (unsigned)(ntiles < 256 ? ntiles : 256);
-#define MGX_W3(DD, SS)                                                                                              \
+#define MGX_W3(MM, SS)                                                                                              \
     do {                                                                                                            \
         static bool allowed = false;                                                                                \
         if (!allowed) {                                                                                             \
-            (void)hipFuncSetAttribute((const void*)wino3_kernel<DD, SS>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+            (void)hipFuncSetAttribute((const void*)wino3_kernel<MM, SS>, hipFuncAttributeMaxDynamicSharedMemorySize, \
                                       W_LDS_BYTES);                                                                 \
             allowed = true;                                                                                         \
         }                                                                                                           \
-        hipLaunchKernelGGL((wino3_kernel<DD, SS>), dim3(grid), dim3(256), W_LDS_BYTES, st, d, x, w, bias, y, dact,   \
+        hipLaunchKernelGGL((wino3_kernel<MM, SS>), dim3(grid), dim3(256), W_LDS_BYTES, st, d, x, w, bias, y, dact,   \
                            ntiles, tiles_h, tiles_w);                                                               \
     } while (0)
-    const int S = d.cin / 32;
-    if (dact) { if (S == 2) MGX_W3(true, 2); else if (S == 3) MGX_W3(true, 3); else MGX_W3(true, 4); }
-    else { if (S == 2) MGX_W3(false, 2); else if (S == 3) MGX_W3(false, 3); else MGX_W3(false, 4); }
+#define MGX_W3S(MM)                                                                                                 \
+    do {                                                                                                            \
+        if (S16 == 2) MGX_W3(MM, 2);                                                                                \
+        else if (S16 == 4) MGX_W3(MM, 4);                                                                           \
+        else if (S16 == 6) MGX_W3(MM, 6);                                                                           \
+        else MGX_W3(MM, 8);                                                                                         \
+    } while (0)
+    const int S16 = d.cin / 16;
+    const bool act = d.act_alpha > 0.f;
+    if (act && dact) MGX_W3S(2);
+    else if (act) MGX_W3S(1);
+    else MGX_W3S(0);
+#undef MGX_W3S
 #undef MGX_W3
     return mgx_launch_status();
 }
