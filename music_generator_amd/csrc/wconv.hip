@@ -10,28 +10,32 @@
 // times the transformed filter U[xi,nu] (k x 32) accumulates into M[xi,nu].  The input channels are
 // consumed in slices of 16: one accumulation step = 8 blocks of 16 MFMAs.
 //
-// On this chip every vector-ALU instruction takes issue cycles away from the fp32 MFMAs of its
-// SIMD, so the kernel is built to execute as few of them as possible:
-//  * the input tile of the NEXT step (18 x 34 positions x 16 channels) travels global -> LDS by
-//    buffer loads with the LDS destination (no registers, no LDS store instructions, zero fill of
-//    the halo outside the image by the buffer range check) while the current step multiplies; two
-//    tile buffers alternate.  A position is 64 bytes; its four 16-byte channel quads are stored
-//    XOR-swizzled with bits 2..3 of the position slot, the even and odd columns of a row apart, so
-//    that the stride-2 patch reads of a 16-lane group cover all 64 banks;
+// On this chip every vector-ALU and vector-memory instruction takes issue cycles away from the fp32
+// MFMAs of its SIMD (measured: a packed add ~8 cycles, a 16-byte buffer load ~70, an LDS store ~40
+// of a 64-cycle MFMA slot), so the kernel is built to execute as few of them as possible:
+//  * the input tile of the NEXT step (18 x 34 positions x 16 channels) is loaded while the current
+//    step multiplies and written to the second of two LDS tile buffers in the same phase: 15
+//    16-byte loads and 15 LDS stores per wave, one per group of 4 MFMAs, all addresses a per-lane
+//    constant plus scalars, the halo outside the image zero-filled by the buffer range check.
+//    (Loads with the LDS as destination need no registers but stall the issuing wave ~120 cycles
+//    each.)  A position is 64 bytes; its four 16-byte channel quads are stored XOR-swizzled with
+//    bits 2..3 of the position slot, the even and odd columns of a row apart, so that the
+//    stride-2 patch reads of a 16-lane group cover all 64 banks;
 //  * V is never stored: a lane builds its fragment from 8 16-byte LDS reads per 4 channels with 16
 //    packed (two floats per lane) additions, slotted between the MFMAs of the previous block;
-//  * all addresses of the main loop are per-lane constants plus immediates or scalars.
+//  * the MFMAs are asm statements that pin the 16 accumulator tiles to the accumulation registers
+//    and the epilogue copies one tile at a time out of them: the compiler's own placement puts all
+//    256 copies behind the last MFMA and spills everything else.
 // U of a 32-channel convolution stays in LDS for the whole kernel; wider inputs stream it one
-// slice ahead (36 dword loads and 35 packed operations per thread and step).  Epilogue: output
-// transform on register pairs (an accumulator register of the 16 tiles is one patch x output
-// channel), bias, tanh(x)+x/alpha, optional derivative store.
+// slice ahead (18 dword loads and 35 packed operations per thread and step).  Epilogue: output
+// transform (an accumulator register of the 16 tiles is one patch x output channel), bias,
+// tanh(x)+x/alpha on register pairs, optional derivative store.
 #include "common.h"
 #include "../../include/mgx.h"
 
 namespace {
 
 typedef float f32x2 __attribute__((ext_vector_type(2)));
-typedef __attribute__((address_space(3))) void* lds_ptr_t;
 
 constexpr int WTH = 16, WTW = 32, WIH = 18;
 constexpr int W_RS = 40;                              // position slots per tile row (34 used)
@@ -39,6 +43,12 @@ constexpr int W_TILE = WIH * W_RS * 16;               // floats per tile buffer 
 constexpr int W_USLICE = 16 * 4 * 128;                // floats of U per 16-channel slice: [xi nu][k/4][n][4]
 constexpr int W_LDS_BYTES = (2 * W_USLICE + 2 * W_TILE) * 4;      // 157 696
 
+__device__ __forceinline__ void mfma_acc(f32x16& acc, float a, float b) {
+    asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, %0" : "+a"(acc) : "v"(a), "v"(b));
+}
+__device__ __forceinline__ void mfma_first(f32x16& acc, float a, float b) {
+    asm volatile("v_mfma_f32_32x32x2_f32 %0, %1, %2, 0" : "=a"(acc) : "v"(a), "v"(b));
+}
 __device__ __forceinline__ f32x2 pk_add(f32x2 a, f32x2 b) {
     f32x2 r;
     asm("v_pk_add_f32 %0, %1, %2" : "=v"(r) : "v"(a), "v"(b));
@@ -64,6 +74,19 @@ __device__ __forceinline__ f32x2 pk_fma(f32x2 a, f32x2 b, f32x2 c) {
 // selects itself, not for the operands of an asm statement: values that go from a transcendental
 // into one of the packed helpers above pass through this first.
 __device__ __forceinline__ void trans_settle(f32x2& v) { asm volatile("s_nop 1" : "+v"(v)); }
+// Copy of an accumulator tile out of the accumulation registers AT THIS POINT of the program: left
+// to the compiler, the copies of all 16 tiles are placed right behind the last MFMA and occupy
+// every vector register before the first of them is used.
+__device__ __forceinline__ f32x16 acc_read16(const f32x16& a) {
+    f32x16 r;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) {
+        float v;
+        asm volatile("v_accvgpr_read_b32 %0, %1" : "=v"(v) : "a"(a[i]));
+        r[i] = v;
+    }
+    return r;
+}
 __device__ __forceinline__ f32x2 pair16(f32x16 v, int k) { return f32x2{v[2 * k], v[2 * k + 1]}; }
 __device__ __forceinline__ f32x16 add16(f32x16 a, f32x16 b) {
     f32x16 r;
@@ -118,13 +141,14 @@ __global__ __launch_bounds__(256, 1) void wino3_kernel(mgx_conv_desc d, const fl
     const int ukq = tid >> 6, un = (tid >> 1) & 31, uhalf = tid & 1;
     const unsigned uvoff = (unsigned)(((ukq * 4 + 2 * uhalf) * 32 + un) * 4);
     float* const ustore = ul + ukq * 128 + un * 4 + 2 * uhalf;
+    auto u_load_tap = [&](int slice, int tap, f32x2 (&g)[9]) {
+        const int soff = ((tap * cin + slice * 16) * 32) * 4;
+        g[tap][0] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rw, uvoff, soff, 0));
+        g[tap][1] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rw, uvoff + 128, soff, 0));
+    };
     auto u_load = [&](int slice, f32x2 (&g)[9]) {
 #pragma unroll
-        for (int tap = 0; tap < 9; ++tap) {
-            const int soff = ((tap * cin + slice * 16) * 32) * 4;
-            g[tap][0] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rw, uvoff, soff, 0));
-            g[tap][1] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rw, uvoff + 128, soff, 0));
-        }
+        for (int tap = 0; tap < 9; ++tap) u_load_tap(slice, tap, g);
     };
     auto u_store = [&](int ubuf, const f32x2 (&g)[9]) {
         const f32x2 half2 = {0.5f, 0.5f};
@@ -171,42 +195,57 @@ __global__ __launch_bounds__(256, 1) void wino3_kernel(mgx_conv_desc d, const fl
         return t;
     };
 
-    // ---- input tile global -> LDS.  Wave w moves tile rows w, w+4, ...; a row is three
+    // ---- input tile global -> registers -> LDS.  Wave w moves tile rows w, w+4, ...; a row is three
     //      instructions of 16 position slots (the third half-masked).  Lane l of an instruction
     //      writes chunk l&3 of slot l>>2 and therefore fetches channel quad (l&3) ^ (slot>>2 & 3)
     //      of the column that slot stands for. ----
-    int dcol[3];
-    unsigned dbase[3];
-#pragma unroll
-    for (int k = 0; k < 3; ++k) {
-        const int sl = 16 * k + (lane >> 2);
-        const int c = sl < 17 ? 2 * sl : 2 * (sl - 17) + 1;
-        const int q = (lane & 3) ^ ((sl >> 2) & 3);
-        dcol[k] = sl < 34 ? c : -0x40000000;           // unused slots: never inside the image
-        dbase[k] = (unsigned)((c * cin + q * 4) * 4);
-    }
     const unsigned band_bytes = (unsigned)WIH * W * cin * 4u;
     const int row_bytes_in = W * cin * 4;
-    auto dma_issue = [&](WTile t, int k16, int buf) {
+    // stage_prepare sets up one tile slice (resources, per-lane source offsets); stage_load(j) and
+    // stage_store(j) are its j-th load and LDS store: issued back to back they stall the wave on the
+    // memory pipeline, so the main loop hands them out one per group of 4 MFMAs.
+    __amdgpu_buffer_rsrc_t ds_rx, ds_rz;
+    unsigned ds_vo[3];
+    int ds_hb = 0, ds_buf = 0;
+    bool ds_on = false;
+    auto stage_prepare = [&](WTile t, int k16, int buf, bool on) {
         const int hb = t.th * WTH - 1, wb = t.tw * WTW - 1;
         const float* origin = x + (((long)t.img * H + hb) * (long)W + wb) * cin + k16 * 16;
-        const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)origin, 0, band_bytes, 0x00020000);
-        const __amdgpu_buffer_rsrc_t rz = __builtin_amdgcn_make_buffer_rsrc((void*)origin, 0, 0, 0x00020000);
-        unsigned vo[3];
+        ds_rx = __builtin_amdgcn_make_buffer_rsrc((void*)origin, 0, band_bytes, 0x00020000);
+        ds_rz = __builtin_amdgcn_make_buffer_rsrc((void*)origin, 0, 0, 0x00020000);
+        ds_hb = hb;
+        ds_buf = buf;
+        ds_on = on;
+        // The per-lane source offsets are re-derived for every slice from one opaque register: kept
+        // live across the tile loop they are the first values the register allocator spills.
+        int ln = lane;
+        asm volatile("" : "+v"(ln));
 #pragma unroll
-        for (int k = 0; k < 3; ++k) vo[k] = (unsigned)(dcol[k] + wb) < (unsigned)W ? dbase[k] : 0x80000000u;
-#pragma unroll
-        for (int i = 0; i < 5; ++i) {
-            const int row = wv + 4 * i;
-            if (row < WIH) {
-                const bool row_ok = (unsigned)(hb + row) < (unsigned)H;
-                const __amdgpu_buffer_rsrc_t rs = row_ok ? rx : rz;
-                const int soff = row * row_bytes_in;
-                float* dst = xt + buf * W_TILE + row * (W_RS * 16);
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr_t)dst, 16, vo[0], soff, 0, 0);
-                __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr_t)(dst + 256), 16, vo[1], soff, 0, 0);
-                if (lane < 32) __builtin_amdgcn_raw_ptr_buffer_load_lds(rs, (lds_ptr_t)(dst + 512), 16, vo[2], soff, 0, 0);
-            }
+        for (int k = 0; k < 3; ++k) {
+            const int sl = 16 * k + ((ln >> 2) & 15);
+            const int c = k == 0 ? 2 * sl : (sl < 17 ? 2 * sl : 2 * sl - 33);
+            const int q = (ln & 3) ^ ((sl >> 2) & 3);
+            const bool ok = (k < 2 || sl < 34) && (unsigned)(c + wb) < (unsigned)W;
+            ds_vo[k] = ok ? (unsigned)((c * cin + q * 4) * 4) : 0x80000000u;
+        }
+    };
+    // Instruction j moves row wv + 4 (j / 3), slot group j % 3, through sv[j].  (Loads with the LDS as
+    // destination would need no registers, but each one stalls the issuing wave for ~120 cycles.)
+    f32x4 sv[15];
+    float* const xs_lane = xt + wv * (W_RS * 16) + lane * 4;
+    auto stage_load = [&](int j) {
+        const int row = wv + 4 * (j / 3), k = j % 3;
+        if (ds_on && row < WIH) {
+            const bool row_ok = (unsigned)(ds_hb + row) < (unsigned)H;
+            const __amdgpu_buffer_rsrc_t rs = row_ok ? ds_rx : ds_rz;
+            sv[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, ds_vo[k], row * row_bytes_in, 0));
+        }
+    };
+    auto stage_store = [&](int j) {
+        const int i = j / 3, k = j % 3;
+        if (ds_on && wv + 4 * i < WIH) {
+            float* dst = xs_lane + ds_buf * W_TILE + i * (4 * W_RS * 16) + k * 256;
+            if (k < 2 || lane < 32) *(f32x4*)dst = sv[j];
         }
     };
 
@@ -228,7 +267,11 @@ __global__ __launch_bounds__(256, 1) void wino3_kernel(mgx_conv_desc d, const fl
     {
         f32x2 g[9];
         u_load(0, g);
-        if (t < ntiles) dma_issue(cur, 0, 0);
+        stage_prepare(cur, 0, 0, t < ntiles);
+#pragma unroll
+        for (int j = 0; j < 15; ++j) stage_load(j);
+#pragma unroll
+        for (int j = 0; j < 15; ++j) stage_store(j);
         u_store(0, g);
         if (kResidentU) {
             u_load(1, g);
@@ -242,22 +285,16 @@ __global__ __launch_bounds__(256, 1) void wino3_kernel(mgx_conv_desc d, const fl
     while (t < ntiles) {
         const WTile nxt = advance(cur);
         const bool next_tile = t + gridDim.x < ntiles;
+        // The MFMAs are asm statements with the accumulator tied to the accumulation registers: the
+        // compiler's own choice moves a 256-register accumulator set into vector registers as soon
+        // as a loop carries it or the unrolled code grows.  The first MFMA of a tile takes 0 as C.
         f32x16 acc[16];
-#pragma unroll
-        for (int p = 0; p < 16; ++p)
-#pragma unroll
-            for (int i = 0; i < 16; ++i) acc[p][i] = 0.f;
-#pragma unroll
-        for (int k16 = 0; k16 < S16; ++k16) {
-            constexpr int kDummy = 0;
-            (void)kDummy;
-            const int buf = k16 & 1, ubuf = k16 & 1;
-            const bool last = k16 + 1 == S16;
+        auto step = [&](const int k16, const int k2, const bool first, const bool last) __attribute__((always_inline)) {
+            const int buf = k2, ubuf = k2;
             const int kn = last ? 0 : k16 + 1;
             // the tile and filter slice of the next step go into the buffers the previous step used
-            if (!last || next_tile) dma_issue(last ? nxt : cur, kn, buf ^ 1);
+            stage_prepare(last ? nxt : cur, kn, buf ^ 1, !last || next_tile);
             f32x2 g[9];
-            if (!kResidentU) u_load(kn, g);
             // ---- 8 blocks (2 channel blocks x 4 row combinations) of 16 MFMAs, software-pipelined:
             //      while block b multiplies, the fragment of block b+1 is transformed in four slices
             //      of 4 packed instructions (one after every 4 MFMAs), the 8 LDS reads of block b+2
@@ -305,7 +342,8 @@ __global__ __launch_bounds__(256, 1) void wino3_kernel(mgx_conv_desc d, const fl
                     const int xi = b & 3, cs = b & 1;
 #pragma unroll
                     for (int c = 0; c < 4; ++c)
-                        acc[xi * 4 + c] = mfma32(V[cs][c][s >> 1][s & 1], uu[cs][c][s], acc[xi * 4 + c]);
+                        if (first && b < 4 && s == 0) mfma_first(acc[xi * 4 + c], V[cs][c][0][0], uu[cs][c][0]);
+                        else mfma_acc(acc[xi * 4 + c], V[cs][c][s >> 1][s & 1], uu[cs][c][s]);
                 };
                 rd(0);
                 ru(0, 0);
@@ -316,58 +354,77 @@ __global__ __launch_bounds__(256, 1) void wino3_kernel(mgx_conv_desc d, const fl
                 rd(1);
                 ru(1, 1);
                 __builtin_amdgcn_sched_barrier(0);
+                // memory instruction slot j = 0..31 (one per group of 4 MFMAs): the 15 tile loads of
+                // the next step first, then the 9 filter taps of the next slice; from slot 17 on the
+                // tile registers go to the LDS buffer the previous step read
+                auto vmem = [&](int j) {
+                    if (j < 15) stage_load(j);
+                    else if (!kResidentU && j < 24) u_load_tap(kn, j - 15, g);
+                    if (j >= 17) stage_store(j - 17);
+                };
 #pragma unroll
                 for (int b = 0; b < 8; ++b) {
                     const int cn = (b & 1) ^ 1;
                     const bool more = b + 1 < 8, more2 = b + 2 < 8;
                     mm(b, 0);
                     if (more) rows(b + 1, 0);
+                    vmem(4 * b);
                     __builtin_amdgcn_sched_barrier(0);
                     mm(b, 1);
                     if (more) rows(b + 1, 2);
+                    vmem(4 * b + 1);
                     __builtin_amdgcn_sched_barrier(0);
                     if (more2) rd(b + 2);
                     mm(b, 2);
                     if (more) cols(cn, 0);
+                    vmem(4 * b + 2);
                     __builtin_amdgcn_sched_barrier(0);
                     mm(b, 3);
                     if (more) cols(cn, 1);
+                    vmem(4 * b + 3);
                     __builtin_amdgcn_sched_barrier(0);
                     if (more2) ru(b + 2, b & 1);
-                    if (!kResidentU && b == 5) {
+                    if (!kResidentU && b == 6) {
                         u_store(ubuf ^ 1, g);
                         __builtin_amdgcn_sched_barrier(0);
                     }
                 }
             }
-            // every load into LDS issued by this wave has landed (they were issued a whole step ago)
-            asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
             if (last) {
                 // ---- epilogue: output transform, bias, activation, stores.  One buffer resource
                 //      per output row clips the columns beyond the image by its range check. ----
                 const int h0 = cur.th * WTH, w0 = cur.tw * WTW;
+                // the compiler does not see the MFMAs: keep the reads of their results clear of the
+                // last one by more than its 16 passes
+                asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 7" ::: "memory");
                 if (h0 + 4 * wv < H) {                     // H is a multiple of 4: a wave is all in or all out
                     const unsigned vbase = (unsigned)(((w0 + 8 * h) * 32 + r) * 4);
                     const float bv = d.nbias > 0 ? bias[r] : 0.f;
                     const f32x2 bv2 = {bv, bv}, ia2 = {inv_alpha, inv_alpha};
-                    // Output transform on whole accumulator tiles (register s of all 16 tiles is one
-                    // patch x output channel), one transform column nu at a time:
-                    // Z_a = A^T M[:, nu] for both output row parities a, then Y[a][b] += Z_a A[nu][b].
+                    // Output transform Y[a][b] = sum over (xi, nu) of At[a][xi] At[b][nu] M[xi][nu] with
+                    // At = [1 1 1 0; 0 1 -1 -1]: every accumulator tile is copied out of the accumulation
+                    // registers once and added to or subtracted from the (at most four) outputs it
+                    // belongs to.  36 tile operations instead of the 24 of the two-stage form, but only
+                    // the four outputs and one tile are live: the two-stage form runs out of registers.
                     f32x16 Y[2][2];
 #pragma unroll
-                    for (int nu = 0; nu < 4; ++nu) {
-                        const f32x16 m0 = acc[nu], m1 = acc[4 + nu], m2 = acc[8 + nu], m3 = acc[12 + nu];
-                        f32x16 z[2];
-                        z[0] = add16(add16(m0, m1), m2);
-                        z[1] = sub16(sub16(m1, m2), m3);
+                    for (int xi = 0; xi < 4; ++xi) {
 #pragma unroll
-                        for (int a = 0; a < 2; ++a) {
-                            if (nu == 0) Y[a][0] = z[a];
-                            if (nu == 1) Y[a][0] = add16(Y[a][0], z[a]), Y[a][1] = z[a];
-                            if (nu == 2) Y[a][0] = add16(Y[a][0], z[a]), Y[a][1] = sub16(Y[a][1], z[a]);
-                            if (nu == 3) Y[a][1] = sub16(Y[a][1], z[a]);
+                        for (int nu = 0; nu < 4; ++nu) {
+                            const f32x16 m = acc_read16(acc[xi * 4 + nu]);
+#pragma unroll
+                            for (int a = 0; a < 2; ++a) {
+                                const int ca = a == 0 ? (xi < 3 ? 1 : 0) : (xi == 0 ? 0 : (xi == 1 ? 1 : -1));
+#pragma unroll
+                                for (int b = 0; b < 2; ++b) {
+                                    const int cb = b == 0 ? (nu < 3 ? 1 : 0) : (nu == 0 ? 0 : (nu == 1 ? 1 : -1));
+                                    if (ca * cb == 0) continue;
+                                    if (xi == a && nu == b) Y[a][b] = m;           // first contribution, always +
+                                    else Y[a][b] = ca * cb > 0 ? add16(Y[a][b], m) : sub16(Y[a][b], m);
+                                }
+                            }
+                            __builtin_amdgcn_sched_barrier(0);
                         }
-                        __builtin_amdgcn_sched_barrier(0);
                     }
 #pragma unroll
                     for (int a = 0; a < 2; ++a) {
@@ -427,6 +484,20 @@ __global__ __launch_bounds__(256, 1) void wino3_kernel(mgx_conv_desc d, const fl
             asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
+        };
+        if (S16 <= 4) {
+#pragma unroll
+            for (int k16 = 0; k16 < S16; ++k16) step(k16, k16 & 1, k16 == 0, k16 + 1 == S16);
+        } else {
+            // more than two step pairs: the first pair apart (it starts the accumulators), the rest
+            // a loop, which also keeps the code inside the instruction cache
+            step(0, 0, true, false);
+            step(1, 1, false, false);
+#pragma unroll 1
+            for (int kk = 2; kk < S16; kk += 2) {
+                step(kk, 0, false, false);
+                step(kk + 1, 1, false, kk + 2 == S16);
+            }
         }
         t += gridDim.x;
         cur = nxt;
