@@ -236,7 +236,9 @@ def test_cabi_rejects_bad_arguments_before_touching_the_device():
     assert need > 0
     assert lib.mgx_conv_wgrad_f32(ctypes.byref(d), fake, fake, None, fake, fake, fake, need - 1, None) \
         == _cabi.MGX_ERR_WORKSPACE
-    assert lib.mgx_conv_route(ctypes.byref(d), 0) == 1 and lib.mgx_conv_route(ctypes.byref(d), 1) == 1
+    # forward: Winograd kernel (tile kernel when switched off), weight gradient: tile kernel
+    assert lib.mgx_conv_route(ctypes.byref(d), 0) == (3 if os.environ.get("MGX_WINOGRAD", "1") != "0" else 1)
+    assert lib.mgx_conv_route(ctypes.byref(d), 1) == 1
     d.hin = d.hout = 4                                   # not a multiple of the 8-row tile
     assert lib.mgx_conv_route(ctypes.byref(d), 0) == 0
     # fused generator block: unset weight pointers, misaligned range, short workspace
