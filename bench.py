@@ -158,6 +158,10 @@ def main():
                 "share_of_step_time": round(ms / args.steps / ms_per_step, 3),
                 "all_contractions_share_of_step_time": round(contraction_ms / args.steps / ms_per_step, 3),
                 "step_tflops_algorithmic": round(STEP_GFLOP_PER_SAMPLE[stage] * args.batch / ms_per_step, 2)}
+    if key == "wino3_kernel":
+        # the kernel's algorithm is Winograd F(2x2,3x3): `achieved` counts the multiply-adds it executes
+        # (16 per 2x2 patch and channel pair); the same launches as a rate of direct-convolution FLOPs:
+        roofline["direct_convolution_equivalent_tflops"] = round(achieved / ops.WINOGRAD_FLOP_FRACTION, 2)
     out = {"metric": "G+D train-step samples/sec", "value": round(value, 3), "unit": "samples/s", "n_gpus": world,
            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
            "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",

@@ -103,7 +103,7 @@ __global__ __launch_bounds__(256) void gblock_pack_kernel(mgx_gblock_weights w, 
         const int s = fr - OFF_W4;
         v = i < 2 ? w.w4[chan(s, h) * 2 + i] : 0.f;
     }
-    pack[idx] = v;
+    pack[frag_slot(fr, lane)] = v;
 }
 
 // ------------------------------------------------------------------------------------------

@@ -24,7 +24,7 @@ namespace {
 // ------------------------------------------------------------------------------------------
 // transposed weight fragments (units of 64 floats)
 // ------------------------------------------------------------------------------------------
-constexpr int PT_W43 = 0;                 // 16 slots: [0] W4, [1..4] W3 rows 0-31, [5..8] W3 rows 32-63, rest 0
+constexpr int PT_W43 = 0;                 // 16 slots: [0] W4, [1..4] W3 rows 0-31, [8..11] W3 rows 32-63, rest 0
 constexpr int PT_W2 = 16;                 // [c 8][it 2][s 16]
 constexpr int PT_W1 = PT_W2 + 256;        // [c 8][ot 4][s 16]
 constexpr int PT_BR = PT_W1 + 512;        // 6 branches x PBR
@@ -46,8 +46,8 @@ __global__ __launch_bounds__(256) void gblock_packT_kernel(mgx_gblock_weights w,
     float v = 0.f;
     if (fr < PT_W2) {
         if (fr == 0) v = i < 8 ? w.w4[i * 2 + h] : 0.f;                       // W4 (8,2)
-        else if (fr <= 8) {                                                   // W3 (64,8)
-            const int ot = (fr - 1) / 4, s = (fr - 1) % 4;
+        else if (fr <= 4 || (fr >= 8 && fr < 12)) {                           // W3 (64,8)
+            const int ot = fr >= 8, s = ot ? fr - 8 : fr - 1;
             v = w.w3[(32 * ot + i) * 8 + s + 4 * h];
         }
     } else if (fr < PT_W1) {                                                  // W2 (256,64)
@@ -81,7 +81,7 @@ __global__ __launch_bounds__(256) void gblock_packT_kernel(mgx_gblock_weights w,
         if (i < 2)
             for (int tap = 0; tap < 4; ++tap) v += w.k0[(tap * 2 + i) * 128 + 32 * it + chan(s, h)];
     }
-    packT[idx] = v;
+    packT[frag_slot(fr, lane)] = v;
 }
 
 __device__ __forceinline__ void zero(f32x16& t) {
@@ -125,7 +125,7 @@ __global__ __launch_bounds__(256, 1) void gblock_dgrad_kernel(const float* __res
             const float o = pvalid ? dy0[(a * (2L * wl) + b) * 2] : 0.f;
             f32x16 dT3, dT2[2];
             zero(dT3); zero(dT2[0]); zero(dT2[1]);
-            pf<1, 4>(B, fptr(packT, PT_W43 + 5), lane);
+            pf<1, 4>(B, fptr(packT, PT_W43 + 8), lane);
             dT3 = mfma32(B.v[0][0], o, dT3);
 #pragma unroll
             for (int s = 0; s < 4; ++s) dT2[0] = mfma32(B.v[0][1 + s], dT3[s], dT2[0]);

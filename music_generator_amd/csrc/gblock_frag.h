@@ -1,10 +1,16 @@
 // Register-fragment helpers shared by the fused generator-block kernels (gblock.hip forward,
-// gblock_bwd.hip data-gradient): weight fragments are 64-float lane-ordered records streamed
-// through two 16-register buffers while the MFMAs of the previous group run.
+// gblock_bwd.hip data-gradient): weight fragments are 64-float records (one float per lane, stored
+// four fragments to a lane-major block) streamed through two 16-register buffers while the MFMAs
+// of the previous group run.
 #pragma once
 #include "common.h"
 
 constexpr int FR = 64;   // floats per fragment (one per lane)
+
+// Position of lane `lane`'s float of fragment `fr` in a packed buffer: fragments are stored in
+// blocks of four, lane-major inside a block, so that a lane fetches its floats of four
+// consecutive fragments with one 16-byte load.  Every fragment group starts at a multiple of 4.
+__host__ __device__ constexpr int frag_slot(int fr, int lane) { return (fr >> 2) * (4 * FR) + lane * 4 + (fr & 3); }
 
 // channel held by accumulator register s in lane half h (= contraction index of MFMA step s)
 __device__ __forceinline__ int chan(int s, int h) { return (s & 3) + 8 * (s >> 2) + 4 * h; }
@@ -29,8 +35,14 @@ __device__ __forceinline__ void pf(WBuf& B, const float* __restrict__ frag, int 
         asm volatile("" ::"v"(B.touch[P]));
         B.touch[P] = frag[16 * FR + (lane & 31) * 32];
     }
+    // four fragments per 16-byte load (frag_slot): a vector-memory instruction costs the issuing
+    // SIMD tens of MFMA cycles whatever its width
 #pragma unroll
-    for (int s = 0; s < NS; ++s) B.v[P][s] = frag[s * FR + lane];
+    for (int q = 0; q < NS / 4; ++q) {
+        const f32x4 t = *(const f32x4*)(frag + q * (4 * FR) + lane * 4);
+#pragma unroll
+        for (int i = 0; i < 4; ++i) B.v[P][4 * q + i] = t[i];
+    }
 }
 
 // acc += sum_{s < NS} B.v[P][s] (A operand: weights) x tile[S0 + s] (B operand: activations)

@@ -113,6 +113,15 @@ def _conv_flops(d: ConvDesc) -> float:
     return 2.0 * d.nimg * d.hout * d.wout * d.kh * d.kw * d.cin * d.ngemm
 
 
+WINOGRAD_FLOP_FRACTION = 16.0 / 36.0
+
+
+def _gemm_flops(d: ConvDesc, key: str) -> float:
+    """FLOPs of the algorithm the launch runs: the direct contraction, or for the Winograd
+    F(2x2,3x3) kernel its 16 multiply-adds per 2x2 output patch and channel pair in place of 36."""
+    return _conv_flops(d) * (WINOGRAD_FLOP_FRACTION if key == "wino3_kernel" else 1.0)
+
+
 def _conv_bytes(d: ConvDesc, n_in: int = 1, n_out: int = 1) -> float:
     """Algorithmic HBM bytes of one contraction launch: every input-shaped operand read once,
     every output-shaped operand written once, the weights once."""
@@ -154,7 +163,8 @@ def conv_gemm(d: ConvDesc, x, w, bias, y, xmul=None, dact=None, accumulate=False
     check(_lib().mgx_conv_gemm_f32(C.byref(d), _p(x), _p(xmul), _p(w), _p(bias) if d.nbias else None,
                                    _p(y), _p(dact), K.stream_ptr()), "mgx_conv_gemm_f32")
     if e0 is not None:
-        PROFILER.stop(_gemm_key(d, xmul is not None), _conv_flops(d), e0,
+        key = _gemm_key(d, xmul is not None)
+        PROFILER.stop(key, _gemm_flops(d, key), e0,
                       _conv_bytes(d, 2 if xmul is not None else 1,
                                   (2 if dact is not None else 1) + (1 if accumulate else 0)))
 
