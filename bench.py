@@ -60,7 +60,12 @@ def measured_traffic(kernel, stage, fade, batch):
         return None
     wl = table.get("stage%d_%s_b%d" % (stage, "fade" if fade else "straight", batch), {})
     entry = wl.get(kernel)
-    return entry["hbm_bytes_per_launch"] if entry else None
+    if entry:
+        return entry["hbm_bytes_per_launch"]
+    # a key without template arguments stands for all instantiations of the kernel: launch-weighted mean
+    inst = [e for k, e in wl.items() if isinstance(e, dict) and k.startswith(kernel + "<")]
+    n = sum(e["launches_per_step"] for e in inst)
+    return round(sum(e["hbm_bytes_per_launch"] * e["launches_per_step"] for e in inst) / n) if n else None
 
 
 def main():
