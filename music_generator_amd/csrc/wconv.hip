@@ -199,7 +199,10 @@ __global__ __launch_bounds__(256, 1) void wino3_kernel(mgx_conv_desc d, const fl
     //      instructions of 16 position slots (the third half-masked).  Lane l of an instruction
     //      writes chunk l&3 of slot l>>2 and therefore fetches channel quad (l&3) ^ (slot>>2 & 3)
     //      of the column that slot stands for. ----
-    const unsigned band_bytes = (unsigned)WIH * W * cin * 4u;
+    // range of the tile's buffer resource, counted from the tile origin (row hb, column wb): the scalar
+    // row offset takes part in the range check, and the last row's positions lie up to 34 columns
+    // behind 18 whole rows (positions outside the image are masked explicitly, not by this range)
+    const unsigned band_bytes = (unsigned)(WIH * W + WTW + 2) * cin * 4u;
     const int row_bytes_in = W * cin * 4;
     // stage_prepare sets up one tile slice (resources, per-lane source offsets); stage_load(j) and
     // stage_store(j) are its j-th load and LDS store: issued back to back they stall the wave on the
@@ -512,7 +515,7 @@ bool mgx_wconv_applicable(const mgx_conv_desc& d) {
     if (d.hin % 4 || d.hin < 8 || d.cin % 32 || d.cin < 32 || d.cin > 128 || d.ngemm != 32 || d.cout != 32) return false;
     if (d.wsn != 1 || d.wsk != 32 || d.wtap != (int64_t)d.cin * 32) return false;
     if (d.nbias != 0 && d.nbias != 32) return false;
-    if ((long)WIH * d.win * d.cin * 4 >= (1L << 31) || (long)d.win * d.ngemm * 4 >= (1L << 31)) return false;
+    if (((long)WIH * d.win + WTW + 2) * d.cin * 4 >= (1L << 31) || (long)d.win * d.ngemm * 4 >= (1L << 31)) return false;
     const long ntiles = (long)d.nimg * ((d.hin + WTH - 1) / WTH) * ((d.win + WTW - 1) / WTW);
     return ntiles < (1L << 31);
 }

@@ -53,6 +53,10 @@ CONV_CASES = [
     (8, 50, 32, 32, (3, 3), (1, 1), "same", 2),
     (16, 70, 128, 32, (3, 3), (1, 1), "same", 2),     # LDS-tiled path, 4 input-channel chunks
     (8, 33, 32, 32, (3, 3), (1, 1), "same", 3),       # LDS-tiled path, ragged right edge
+    (12, 45, 64, 32, (3, 3), (1, 1), "same", 2),      # Winograd kernel: 4 channel steps, partial second tile row
+    (24, 40, 96, 32, (3, 3), (1, 1), "same", 1),      # Winograd kernel: 6 channel steps (rolled step loop)
+    (20, 33, 32, 32, (3, 3), (1, 1), "same", 2),      # Winograd kernel: 4 valid rows in the last tile row
+    (16, 640, 32, 32, (3, 3), (1, 1), "same", 14),    # Winograd kernel: 280 tiles, workgroups walk two tiles
     (24, 95, 32, 32, (2, 2), (1, 1), "same", 1),
     (8, 50, 32, 32, (2, 2), (1, 1), "same", 2),       # 2x2 'same': pad 0 before / 1 after
     (8, 52, 32, 32, (2, 2), (2, 2), "valid", 3),
