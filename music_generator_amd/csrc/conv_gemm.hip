@@ -304,12 +304,10 @@ int launch_pointwise2(const mgx_conv_desc& d, const float* x, const float* w, co
 bool mgx_pointwise2_applicable(const mgx_conv_desc& d) { return pointwise2_applicable(d, nullptr); }
 
 // The Winograd forward kernel is used unless the environment says MGX_WINOGRAD=0 (read once).
+// read at every call: a process can compare the two kernels on the same operands
 bool mgx_wconv_enabled() {
-    static const bool on = [] {
-        const char* e = getenv("MGX_WINOGRAD");
-        return !(e && e[0] == '0');
-    }();
-    return on;
+    const char* e = getenv("MGX_WINOGRAD");
+    return !(e && e[0] == '0');
 }
 
 extern "C" int mgx_conv_gemm_f32(const mgx_conv_desc* dp, const float* x, const float* xmul, const float* w,

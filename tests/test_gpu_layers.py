@@ -83,6 +83,35 @@ def test_conv2d(case, act):
     _check(build, oracle, (h, w, ci), batch)
 
 
+@pytest.mark.parametrize("ci", [32, 128])
+def test_winograd_equals_direct_kernel_at_full_size(ci, monkeypatch):
+    """Size-independent check at the benchmark's shapes (batch 64, 32x6000, too large for the float64
+    oracle): the Winograd kernel and the direct tile kernel are two float32 evaluations of the same
+    convolution + tanh(x)+x/alpha, output and saved derivative.  Tolerance: relative L2 <= 2e-6 (each
+    kernel is within ~4e-7 of float64 at the oracle's sizes), max abs <= 2e-5 * max|y|."""
+    n, h, w = 64, 32, 6000
+    inp = Input(shape=(h, w, ci))
+    t = L.Conv2D(32, (3, 3), padding="same", kernel_initializer="he_normal")(inp)
+    model = Model(inp, M.SoftRectifier(start_alpha=20000.0)(t))
+    randomize(model, 3)
+    x = torch.rand((n, h, w, ci), device="cuda") * 2 - 1
+    outs = []
+    for flag in ("1", "0"):
+        monkeypatch.setenv("MGX_WINOGRAD", flag)
+        y, tape = model.forward(x, save=True)
+        saved = [v for entry in tape if isinstance(entry, tuple) for v in entry if isinstance(v, torch.Tensor)]
+        outs.append((y.clone(), [v.clone() for v in saved if v.shape == y.shape and v.data_ptr() not in (y.data_ptr(), x.data_ptr())]))
+        del y, tape, saved
+    (ya, sa), (yb, sb) = outs
+    pairs = [(ya, yb)] + list(zip(sa, sb))
+    assert len(sa) == len(sb) == 1          # the saved derivative of the fused activation
+    for a, b in pairs:
+        diff = (a - b).double()
+        rel = float(diff.norm() / b.double().norm())
+        assert rel <= 2e-6, rel
+        assert float(diff.abs().max()) <= 2e-5 * float(b.abs().max())
+
+
 CONVT_CASES = [
     (4, 50, 128, 16, (2, 1), 3), (8, 50, 32, 64, (1, 2), 2), (4, 50, 32, 64, (1, 15), 2),
     (1, 50, 128, 4, (2, 1), 3), (2, 50, 8, 16, (2, 1), 3),
