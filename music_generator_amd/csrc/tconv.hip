@@ -46,53 +46,60 @@ __device__ __forceinline__ Tile decode_tile(long t, int tiles_h, int tiles_w) {
     return q;
 }
 
-// Stage channels [c0, c0+32) of the (IH x IW) input window of a tile into LDS, stride `pstr`.
-// Every load is unconditional (out-of-image positions read a clamped, valid address and are then
-// replaced by zeros) so that the loads of one batch are issued back to back instead of being
-// branched around and waited for one by one.
+// Stage channels [c0, c0+32) of the (IH x IW) window of a tile into LDS as [position][32], times
+// `xmul` when MUL.  Thread (column tid/8, channel quad tid%8) moves its quad of every window row:
+// one per-thread offset (out-of-image columns point outside the buffer range and read as zeros),
+// the row is a scalar offset, rows outside the image use an empty buffer.  The columns beyond 32
+// are one more load of the first (IW-32)*IH*8 threads.  No per-load address arithmetic: vector-ALU
+// instructions take issue time from the MFMAs of the co-resident workgroup.
 template <int IH, int IW, bool MUL>
-__device__ __forceinline__ void stage_tile(float* lds, int pstr, const float* __restrict__ x,
-                                           const float* __restrict__ xmul, long img, int hbase, int wbase, int H,
-                                           int W, int ctot, int c0) {
-    constexpr int NPIX = IH * IW;
-    constexpr int ITER = (NPIX + 31) / 32;
-    constexpr int BATCH = 4;   // float4 loads in flight per thread (bounds the staging registers)
-    const int c4 = threadIdx.x & 7;
-    const int p0 = threadIdx.x >> 3;
-    const long imgbase = img * H;
+__device__ __forceinline__ void stage_tile(float* lds, const float* __restrict__ x, const float* __restrict__ xmul,
+                                           long img, int hbase, int wbase, int H, int W, int ctot, int c0) {
+    constexpr int ROWB = 4;                               // rows in flight (bounds the staging registers)
+    constexpr int XC = IW - 32;                           // columns beyond the 32 of the main pass
+    constexpr int NRES = XC * IH * 8;
+    const int tid = threadIdx.x, c4 = tid & 7, col = tid >> 3;
+    const long origin = ((img * H + hbase) * (long)W + wbase) * ctot + c0;
+    // the scalar row offset takes part in the range check: the range spans the whole window
+    const unsigned range = (unsigned)((IH * W + IW) * ctot * 4);
+    const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)(x + origin), 0, range, 0x00020000);
+    const __amdgpu_buffer_rsrc_t rz = __builtin_amdgcn_make_buffer_rsrc((void*)(x + origin), 0, 0, 0x00020000);
+    const __amdgpu_buffer_rsrc_t mx =
+        __builtin_amdgcn_make_buffer_rsrc((void*)((MUL ? xmul : x) + origin), 0, range, 0x00020000);
+    const __amdgpu_buffer_rsrc_t mz =
+        __builtin_amdgcn_make_buffer_rsrc((void*)((MUL ? xmul : x) + origin), 0, 0, 0x00020000);
+    const unsigned vmain = (unsigned)(col + wbase) < (unsigned)W ? (unsigned)((col * ctot + c4 * 4) * 4) : 0x80000000u;
+    const int row_bytes = W * ctot * 4;
+    float* dst = lds + col * 32 + c4 * 4;
 #pragma unroll
-    for (int i0 = 0; i0 < ITER; i0 += BATCH) {
-        f32x4 v[BATCH], m[BATCH];
-        bool ok[BATCH];
+    for (int i0 = 0; i0 < IH; i0 += ROWB) {
+        f32x4 v[ROWB], m[ROWB];
 #pragma unroll
-        for (int j = 0; j < BATCH; ++j) {
-            if (i0 + j < ITER) {
-                const int px = p0 + 32 * (i0 + j);
-                const int ty = px / IW, tx = px - ty * IW;
-                const int hi = hbase + ty, wi = wbase + tx;
-                ok[j] = px < NPIX && hi >= 0 && hi < H && wi >= 0 && wi < W;
-                const int hc = min(max(hi, 0), H - 1), wc = min(max(wi, 0), W - 1);
-                const long off = ((imgbase + hc) * W + wc) * (long)ctot + c0 + c4 * 4;
-                v[j] = *(const f32x4*)(x + off);
-                if (MUL) m[j] = *(const f32x4*)(xmul + off);
+        for (int j = 0; j < ROWB; ++j) {
+            if (i0 + j < IH) {
+                const bool row_ok = (unsigned)(hbase + i0 + j) < (unsigned)H;          // uniform
+                v[j] = __builtin_bit_cast(
+                    f32x4, __builtin_amdgcn_raw_buffer_load_b128(row_ok ? rx : rz, vmain, (i0 + j) * row_bytes, 0));
+                if (MUL)
+                    m[j] = __builtin_bit_cast(
+                        f32x4, __builtin_amdgcn_raw_buffer_load_b128(row_ok ? mx : mz, vmain, (i0 + j) * row_bytes, 0));
             }
         }
 #pragma unroll
-        for (int j = 0; j < BATCH; ++j) {
-            if (i0 + j < ITER) {
-                const int px = p0 + 32 * (i0 + j);
-                f32x4 val = v[j];
-                if (MUL) val *= m[j];
-                if (!ok[j]) val = (f32x4){0.f, 0.f, 0.f, 0.f};
-                if (px < NPIX) *(f32x4*)(lds + px * pstr + c4 * 4) = val;
-            }
-        }
+        for (int j = 0; j < ROWB; ++j)
+            if (i0 + j < IH) *(f32x4*)(dst + (i0 + j) * IW * 32) = MUL ? v[j] * m[j] : v[j];
+    }
+    if (NRES > 0) {
+        const int rrow = tid / (XC * 8), rem = tid - rrow * (XC * 8);
+        const int rcol = 32 + (rem >> 3), rq = rem & 7;
+        const bool ok = tid < NRES && (unsigned)(hbase + rrow) < (unsigned)H && (unsigned)(rcol + wbase) < (unsigned)W;
+        const unsigned vres = ok ? (unsigned)(((rrow * W + rcol) * ctot + rq * 4) * 4) : 0x80000000u;
+        f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, vres, 0, 0));
+        if (MUL) v *= __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(mx, vres, 0, 0));
+        if (tid < NRES) *(f32x4*)(lds + (rrow * IW + rcol) * 32 + rq * 4) = v;
     }
 }
 
-// ------------------------------------------------------------------------------------------
-// weight gradient: dW[tap][ci][co] = sum_px X[px+tap][ci] * dP[px][co], ci chunk = blockIdx.y
-// ------------------------------------------------------------------------------------------
 template <int KH, int KW>
 constexpr int twgrad_lds_bytes() { return ((TH + KH - 1) * (TW + KW - 1) + TH * TW) * 32 * 4; }
 
@@ -122,9 +129,9 @@ __global__ __launch_bounds__(256, 2) void twgrad_kernel(mgx_conv_desc d, const f
     for (long t = blockIdx.x; t < ntiles; t += gridDim.x) {
         const Tile q = decode_tile(t, tiles_h, tiles_w);
         __syncthreads();
-        stage_tile<IH, IW, false>(xl, 32, x, nullptr, q.img, q.h0 - d.pt, q.w0 - d.pl, H, W, d.cin, kc * 32);
-        if (dymul) stage_tile<TH, TW, true>(gl, 32, dy, dymul, q.img, q.h0, q.w0, H, W, d.ngemm, 0);
-        else stage_tile<TH, TW, false>(gl, 32, dy, dymul, q.img, q.h0, q.w0, H, W, d.ngemm, 0);
+        stage_tile<IH, IW, false>(xl, x, nullptr, q.img, q.h0 - d.pt, q.w0 - d.pl, H, W, d.cin, kc * 32);
+        if (dymul) stage_tile<TH, TW, true>(gl, dy, dymul, q.img, q.h0, q.w0, H, W, d.ngemm, 0);
+        else stage_tile<TH, TW, false>(gl, dy, dymul, q.img, q.h0, q.w0, H, W, d.ngemm, 0);
         __syncthreads();
 #pragma unroll 4
         for (int pp = 0; pp < 32; ++pp) {
