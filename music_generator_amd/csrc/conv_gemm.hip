@@ -13,9 +13,9 @@
 #include "../../include/mgx.h"
 
 bool mgx_tconv_applicable(const mgx_conv_desc& d);
-bool mgx_wconv_applicable(const mgx_conv_desc& d);
-int mgx_wconv_launch(const mgx_conv_desc& d, const float* x, const float* w, const float* bias, float* y, float* dact,
-                     hipStream_t st);
+bool mgx_wconv_applicable(const mgx_conv_desc& d, bool mul);
+int mgx_wconv_launch(const mgx_conv_desc& d, const float* x, const float* xmul, const float* w, const float* bias,
+                     float* y, float* dact, hipStream_t st);
 int mgx_tconv_launch(const mgx_conv_desc& d, const float* x, const float* xmul, const float* w, const float* bias,
                      float* y, float* dact, hipStream_t st);
 
@@ -322,7 +322,8 @@ extern "C" int mgx_conv_gemm_f32(const mgx_conv_desc* dp, const float* x, const 
     // the last gather position of every row grid must be reachable by construction of the layer:
     // out-of-range positions are treated as zero padding, never dereferenced.
     hipStream_t st = (hipStream_t)stream;
-    if (!xmul && mgx_wconv_enabled() && mgx_wconv_applicable(d)) return mgx_wconv_launch(d, x, w, bias, y, dact, st);
+    if (mgx_wconv_enabled() && mgx_wconv_applicable(d, xmul != nullptr))
+        return mgx_wconv_launch(d, x, xmul, w, bias, y, dact, st);
     if (mgx_tconv_applicable(d)) return mgx_tconv_launch(d, x, xmul, w, bias, y, dact, st);
     if (pointwise2_applicable(d, xmul)) return launch_pointwise2(d, x, w, bias, y, dact, st);
     const int ntiles = (d.ngemm + 31) / 32;

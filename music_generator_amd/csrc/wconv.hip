@@ -119,8 +119,10 @@ struct WTile {
 // MODE 0: linear output, 1: tanh(x)+x/alpha, 2: the same and the derivative stored to dact.
 // S16 = cin / 16 accumulation steps per tile (unrolled: the 16 accumulator tiles must not be
 // carried around a rolled loop; S16 is even, so the buffer of a step is a compile-time constant).
-template <int MODE, int S16>
+// MUL: the input is x * xmul elementwise (data-gradients: dy times the saved activation derivative).
+template <int MODE, int S16, bool MUL>
 __global__ __launch_bounds__(256, 1) void wino3_kernel(mgx_conv_desc d, const float* __restrict__ x,
+                                                       const float* __restrict__ xmul,
                                                        const float* __restrict__ w,
                                                        const float* __restrict__ bias, float* __restrict__ y,
                                                        float* __restrict__ dact, long ntiles, int tiles_h,
@@ -136,15 +138,18 @@ __global__ __launch_bounds__(256, 1) void wino3_kernel(mgx_conv_desc d, const fl
 
     // ---- transformed filter of a 16-channel slice: thread (kq, n, half) owns 2 input channels x 1
     //      output channel; the 18 addresses are one per-thread offset plus a scalar ----
+    //      Weight of (tap, input channel k, output channel n) at w[tap' * wtap + k * wsk + n * wsn],
+    //      tap' = 8 - tap for a flipped (data-gradient) filter.
     const __amdgpu_buffer_rsrc_t rw =
         __builtin_amdgcn_make_buffer_rsrc((void*)w, 0, (unsigned)(9 * cin * 32 * 4), 0x00020000);
     const int ukq = tid >> 6, un = (tid >> 1) & 31, uhalf = tid & 1;
-    const unsigned uvoff = (unsigned)(((ukq * 4 + 2 * uhalf) * 32 + un) * 4);
+    const unsigned uvoff = (unsigned)(((ukq * 4 + 2 * uhalf) * d.wsk + un * d.wsn) * 4);
+    const unsigned uvoff1 = uvoff + (unsigned)(d.wsk * 4);
     float* const ustore = ul + ukq * 128 + un * 4 + 2 * uhalf;
     auto u_load_tap = [&](int slice, int tap, f32x2 (&g)[9]) {
-        const int soff = ((tap * cin + slice * 16) * 32) * 4;
+        const int soff = (((d.flip ? 8 - tap : tap) * (int)d.wtap) + slice * 16 * d.wsk) * 4;
         g[tap][0] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rw, uvoff, soff, 0));
-        g[tap][1] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rw, uvoff + 128, soff, 0));
+        g[tap][1] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rw, uvoff1, soff, 0));
     };
     auto u_load = [&](int slice, f32x2 (&g)[9]) {
 #pragma unroll
@@ -207,7 +212,7 @@ __global__ __launch_bounds__(256, 1) void wino3_kernel(mgx_conv_desc d, const fl
     // stage_prepare sets up one tile slice (resources, per-lane source offsets); stage_load(j) and
     // stage_store(j) are its j-th load and LDS store: issued back to back they stall the wave on the
     // memory pipeline, so the main loop hands them out one per group of 4 MFMAs.
-    __amdgpu_buffer_rsrc_t ds_rx, ds_rz;
+    __amdgpu_buffer_rsrc_t ds_rx, ds_rz, ds_mx, ds_mz;
     unsigned ds_vo[3];
     int ds_hb = 0, ds_buf = 0;
     bool ds_on = false;
@@ -216,6 +221,11 @@ __global__ __launch_bounds__(256, 1) void wino3_kernel(mgx_conv_desc d, const fl
         const float* origin = x + (((long)t.img * H + hb) * (long)W + wb) * cin + k16 * 16;
         ds_rx = __builtin_amdgcn_make_buffer_rsrc((void*)origin, 0, band_bytes, 0x00020000);
         ds_rz = __builtin_amdgcn_make_buffer_rsrc((void*)origin, 0, 0, 0x00020000);
+        if (MUL) {
+            const float* morigin = xmul + (origin - x);
+            ds_mx = __builtin_amdgcn_make_buffer_rsrc((void*)morigin, 0, band_bytes, 0x00020000);
+            ds_mz = __builtin_amdgcn_make_buffer_rsrc((void*)morigin, 0, 0, 0x00020000);
+        }
         ds_hb = hb;
         ds_buf = buf;
         ds_on = on;
@@ -234,7 +244,7 @@ __global__ __launch_bounds__(256, 1) void wino3_kernel(mgx_conv_desc d, const fl
     };
     // Instruction j moves row wv + 4 (j / 3), slot group j % 3, through sv[j].  (Loads with the LDS as
     // destination would need no registers, but each one stalls the issuing wave for ~120 cycles.)
-    f32x4 sv[15];
+    f32x4 sv[15], sm[MUL ? 15 : 1];
     float* const xs_lane = xt + wv * (W_RS * 16) + lane * 4;
     auto stage_load = [&](int j) {
         const int row = wv + 4 * (j / 3), k = j % 3;
@@ -242,13 +252,16 @@ __global__ __launch_bounds__(256, 1) void wino3_kernel(mgx_conv_desc d, const fl
             const bool row_ok = (unsigned)(ds_hb + row) < (unsigned)H;
             const __amdgpu_buffer_rsrc_t rs = row_ok ? ds_rx : ds_rz;
             sv[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rs, ds_vo[k], row * row_bytes_in, 0));
+            if (MUL)
+                sm[j] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(row_ok ? ds_mx : ds_mz, ds_vo[k],
+                                                                                         row * row_bytes_in, 0));
         }
     };
     auto stage_store = [&](int j) {
         const int i = j / 3, k = j % 3;
         if (ds_on && wv + 4 * i < WIH) {
             float* dst = xs_lane + ds_buf * W_TILE + i * (4 * W_RS * 16) + k * 256;
-            if (k < 2 || lane < 32) *(f32x4*)dst = sv[j];
+            if (k < 2 || lane < 32) *(f32x4*)dst = MUL ? sv[j] * sm[j] : sv[j];
         }
     };
 
@@ -508,44 +521,49 @@ __global__ __launch_bounds__(256, 1) void wino3_kernel(mgx_conv_desc d, const fl
 }
 
 }  // namespace
-// Forward 3x3 'same' convolutions with 32 output channels that the Winograd kernel covers.
-bool mgx_wconv_applicable(const mgx_conv_desc& d) {
+// 3x3 'same' convolutions with 32 output channels that the Winograd kernel covers: forward layout
+// (weights [tap][k][n]) or data-gradient layout ([tap][n][k], flipped taps); with an input
+// multiplier only the 32-channel linear case (the data-gradients of the discriminator blocks).
+bool mgx_wconv_applicable(const mgx_conv_desc& d, bool mul) {
     if (d.kh != 3 || d.kw != 3 || d.sh != 1 || d.sw != 1 || d.dkh != 1 || d.dkw != 1) return false;
-    if (d.pt != 1 || d.pl != 1 || d.hout != d.hin || d.wout != d.win || d.flip || d.accumulate) return false;
+    if (d.pt != 1 || d.pl != 1 || d.hout != d.hin || d.wout != d.win || d.accumulate) return false;
     if (d.hin % 4 || d.hin < 8 || d.cin % 32 || d.cin < 32 || d.cin > 128 || d.ngemm != 32 || d.cout != 32) return false;
-    if (d.wsn != 1 || d.wsk != 32 || d.wtap != (int64_t)d.cin * 32) return false;
+    const bool fwd_layout = d.wsn == 1 && d.wsk == 32, bwd_layout = d.wsk == 1 && d.wsn == d.cin;
+    if (!(fwd_layout || bwd_layout) || d.wtap != (int64_t)d.cin * 32) return false;
+    if (mul && (d.cin != 32 || d.act_alpha > 0.f)) return false;
     if (d.nbias != 0 && d.nbias != 32) return false;
     if (((long)WIH * d.win + WTW + 2) * d.cin * 4 >= (1L << 31) || (long)d.win * d.ngemm * 4 >= (1L << 31)) return false;
     const long ntiles = (long)d.nimg * ((d.hin + WTH - 1) / WTH) * ((d.win + WTW - 1) / WTW);
     return ntiles < (1L << 31);
 }
 
-int mgx_wconv_launch(const mgx_conv_desc& d, const float* x, const float* w, const float* bias, float* y, float* dact,
-                     hipStream_t st) {
+int mgx_wconv_launch(const mgx_conv_desc& d, const float* x, const float* xmul, const float* w, const float* bias,
+                     float* y, float* dact, hipStream_t st) {
     const int tiles_h = (d.hin + WTH - 1) / WTH, tiles_w = (d.win + WTW - 1) / WTW;
     const long ntiles = (long)d.nimg * tiles_h * tiles_w;
     const unsigned grid = (unsigned)(ntiles < 256 ? ntiles : 256);
-#define MGX_W3(MM, SS)                                                                                              \
+#define MGX_W3(MM, SS, UU)                                                                                          \
     do {                                                                                                            \
         static bool allowed = false;                                                                                \
         if (!allowed) {                                                                                             \
-            (void)hipFuncSetAttribute((const void*)wino3_kernel<MM, SS>, hipFuncAttributeMaxDynamicSharedMemorySize, \
-                                      W_LDS_BYTES);                                                                 \
+            (void)hipFuncSetAttribute((const void*)wino3_kernel<MM, SS, UU>,                                        \
+                                      hipFuncAttributeMaxDynamicSharedMemorySize, W_LDS_BYTES);                     \
             allowed = true;                                                                                         \
         }                                                                                                           \
-        hipLaunchKernelGGL((wino3_kernel<MM, SS>), dim3(grid), dim3(256), W_LDS_BYTES, st, d, x, w, bias, y, dact,   \
-                           ntiles, tiles_h, tiles_w);                                                               \
+        hipLaunchKernelGGL((wino3_kernel<MM, SS, UU>), dim3(grid), dim3(256), W_LDS_BYTES, st, d, x, xmul, w, bias, \
+                           y, dact, ntiles, tiles_h, tiles_w);                                                      \
     } while (0)
 #define MGX_W3S(MM)                                                                                                 \
     do {                                                                                                            \
-        if (S16 == 2) MGX_W3(MM, 2);                                                                                \
-        else if (S16 == 4) MGX_W3(MM, 4);                                                                           \
-        else if (S16 == 6) MGX_W3(MM, 6);                                                                           \
-        else MGX_W3(MM, 8);                                                                                         \
+        if (S16 == 2) MGX_W3(MM, 2, false);                                                                         \
+        else if (S16 == 4) MGX_W3(MM, 4, false);                                                                    \
+        else if (S16 == 6) MGX_W3(MM, 6, false);                                                                    \
+        else MGX_W3(MM, 8, false);                                                                                  \
     } while (0)
     const int S16 = d.cin / 16;
     const bool act = d.act_alpha > 0.f;
-    if (act && dact) MGX_W3S(2);
+    if (xmul) MGX_W3(0, 2, true);
+    else if (act && dact) MGX_W3S(2);
     else if (act) MGX_W3S(1);
     else MGX_W3S(0);
 #undef MGX_W3S

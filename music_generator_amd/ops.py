@@ -79,12 +79,12 @@ def _hbm_op(name):
 
 
 def _gemm_key(d: ConvDesc, mul: bool = False) -> str:
-    route = _lib().mgx_conv_route(C.byref(d), 0)
+    route = _lib().mgx_conv_route(C.byref(d), 2 if mul else 0)
     if route == 2 and not mul:
         return "pointwise2_kernel"
-    if route == 3 and not mul:
+    if route == 3:
         return "wino3_kernel"
-    if route in (1, 3):
+    if route == 1:
         return "tconv3_kernel<%d,%d,%s,%s>" % (d.kh, d.kw, "true" if d.wsk == 1 else "false",
                                                "true" if mul else "false")
     nt = (d.ngemm + 31) // 32
