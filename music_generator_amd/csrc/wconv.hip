@@ -120,7 +120,9 @@ struct WTile {
 // S16 = cin / 16 accumulation steps per tile (unrolled: the 16 accumulator tiles must not be
 // carried around a rolled loop; S16 is even, so the buffer of a step is a compile-time constant).
 // MUL: the input is x * xmul elementwise (data-gradients: dy times the saved activation derivative).
-template <int MODE, int S16, bool MUL>
+// OSTR: floats between output positions (a launch computes 32 of the OSTR output channels; y, w and
+// bias arrive offset to the launch's first channel).
+template <int MODE, int S16, bool MUL, int OSTR>
 __global__ __launch_bounds__(256, 1) void wino3_kernel(mgx_conv_desc d, const float* __restrict__ x,
                                                        const float* __restrict__ xmul,
                                                        const float* __restrict__ w,
@@ -141,7 +143,7 @@ __global__ __launch_bounds__(256, 1) void wino3_kernel(mgx_conv_desc d, const fl
     //      Weight of (tap, input channel k, output channel n) at w[tap' * wtap + k * wsk + n * wsn],
     //      tap' = 8 - tap for a flipped (data-gradient) filter.
     const __amdgpu_buffer_rsrc_t rw =
-        __builtin_amdgcn_make_buffer_rsrc((void*)w, 0, (unsigned)(9 * cin * 32 * 4), 0x00020000);
+        __builtin_amdgcn_make_buffer_rsrc((void*)w, 0, (unsigned)(9 * d.wtap * 4), 0x00020000);
     const int ukq = tid >> 6, un = (tid >> 1) & 31, uhalf = tid & 1;
     const unsigned uvoff = (unsigned)(((ukq * 4 + 2 * uhalf) * d.wsk + un * d.wsn) * 4);
     const unsigned uvoff1 = uvoff + (unsigned)(d.wsk * 4);
@@ -277,7 +279,7 @@ __global__ __launch_bounds__(256, 1) void wino3_kernel(mgx_conv_desc d, const fl
     }
     const float* ubase = ul + h * 128 + r * 4;
     const float inv_alpha = d.act_alpha > 0.f ? 1.0f / d.act_alpha : 0.f;
-    const unsigned out_row_bytes = (unsigned)W * 32u * 4u;
+    const unsigned out_row_bytes = (unsigned)W * (unsigned)OSTR * 4u;
 
     long t = blockIdx.x;
     {
@@ -414,7 +416,7 @@ __global__ __launch_bounds__(256, 1) void wino3_kernel(mgx_conv_desc d, const fl
                 // last one by more than its 16 passes
                 asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 7" ::: "memory");
                 if (h0 + 4 * wv < H) {                     // H is a multiple of 4: a wave is all in or all out
-                    const unsigned vbase = (unsigned)(((w0 + 8 * h) * 32 + r) * 4);
+                    const unsigned vbase = (unsigned)(((w0 + 8 * h) * OSTR + r) * 4);
                     const float bv = d.nbias > 0 ? bias[r] : 0.f;
                     const f32x2 bv2 = {bv, bv}, ia2 = {inv_alpha, inv_alpha};
                     // Output transform Y[a][b] = sum over (xi, nu) of At[a][xi] At[b][nu] M[xi][nu] with
@@ -446,7 +448,7 @@ __global__ __launch_bounds__(256, 1) void wino3_kernel(mgx_conv_desc d, const fl
                     for (int a = 0; a < 2; ++a) {
 #pragma unroll
                         for (int trs = 0; trs < 2; ++trs) {                         // patch row of registers 8 trs ..
-                            const long rowoff = (((long)cur.img * H + h0 + 4 * wv + 2 * trs + a) * (long)W) * 32;
+                            const long rowoff = (((long)cur.img * H + h0 + 4 * wv + 2 * trs + a) * (long)W) * OSTR;
                             const __amdgpu_buffer_rsrc_t ry =
                                 __builtin_amdgcn_make_buffer_rsrc((void*)(y + rowoff), 0, out_row_bytes, 0x00020000);
                             const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc(
@@ -485,10 +487,10 @@ __global__ __launch_bounds__(256, 1) void wino3_kernel(mgx_conv_desc d, const fl
                                         // (a bit_cast applied directly to a vector element reads element 0)
                                         const float vs = v[e2], ds = der[e2];
                                         __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, vs), ry,
-                                                                              vbase + cu * 128, 0, 0);
+                                                                              vbase + cu * (OSTR * 4), 0, 0);
                                         if (MODE == 2)
                                             __builtin_amdgcn_raw_buffer_store_b32(__builtin_bit_cast(unsigned, ds), rd,
-                                                                                  vbase + cu * 128, 0, 0);
+                                                                                  vbase + cu * (OSTR * 4), 0, 0);
                                     }
                                 }
                                 __builtin_amdgcn_sched_barrier(0);
@@ -521,17 +523,20 @@ __global__ __launch_bounds__(256, 1) void wino3_kernel(mgx_conv_desc d, const fl
 }
 
 }  // namespace
-// 3x3 'same' convolutions with 32 output channels that the Winograd kernel covers: forward layout
-// (weights [tap][k][n]) or data-gradient layout ([tap][n][k], flipped taps); with an input
-// multiplier only the 32-channel linear case (the data-gradients of the discriminator blocks).
+// 3x3 'same' convolutions that the Winograd kernel covers: 32 output channels in the forward layout
+// (weights [tap][k][n]) or the data-gradient layout ([tap][n][k], flipped taps); with an input
+// multiplier (the data-gradients of the discriminator blocks: 32 input channels, no activation) also
+// 64..128 output channels, computed 32 at a time by one launch each.
 bool mgx_wconv_applicable(const mgx_conv_desc& d, bool mul) {
     if (d.kh != 3 || d.kw != 3 || d.sh != 1 || d.sw != 1 || d.dkh != 1 || d.dkw != 1) return false;
     if (d.pt != 1 || d.pl != 1 || d.hout != d.hin || d.wout != d.win || d.accumulate) return false;
-    if (d.hin % 4 || d.hin < 8 || d.cin % 32 || d.cin < 32 || d.cin > 128 || d.ngemm != 32 || d.cout != 32) return false;
-    const bool fwd_layout = d.wsn == 1 && d.wsk == 32, bwd_layout = d.wsk == 1 && d.wsn == d.cin;
-    if (!(fwd_layout || bwd_layout) || d.wtap != (int64_t)d.cin * 32) return false;
-    if (mul && (d.cin != 32 || d.act_alpha > 0.f)) return false;
-    if (d.nbias != 0 && d.nbias != 32) return false;
+    if (d.hin % 4 || d.hin < 8 || d.cin % 32 || d.cin < 32 || d.cin > 128 || d.cout != d.ngemm) return false;
+    if (mul) {
+        if (d.cin != 32 || d.act_alpha > 0.f || (d.ngemm != 32 && d.ngemm != 128)) return false;
+    } else if (d.ngemm != 32) return false;
+    const bool fwd_layout = d.wsn == 1 && d.wsk == d.ngemm, bwd_layout = d.wsk == 1 && d.wsn == d.cin;
+    if (!(fwd_layout || bwd_layout) || d.wtap != (int64_t)d.cin * d.ngemm) return false;
+    if (d.nbias != 0 && d.nbias != d.ngemm) return false;
     if (((long)WIH * d.win + WTW + 2) * d.cin * 4 >= (1L << 31) || (long)d.win * d.ngemm * 4 >= (1L << 31)) return false;
     const long ntiles = (long)d.nimg * ((d.hin + WTH - 1) / WTH) * ((d.win + WTW - 1) / WTW);
     return ntiles < (1L << 31);
@@ -542,27 +547,31 @@ int mgx_wconv_launch(const mgx_conv_desc& d, const float* x, const float* xmul, 
     const int tiles_h = (d.hin + WTH - 1) / WTH, tiles_w = (d.win + WTW - 1) / WTW;
     const long ntiles = (long)d.nimg * tiles_h * tiles_w;
     const unsigned grid = (unsigned)(ntiles < 256 ? ntiles : 256);
-#define MGX_W3(MM, SS, UU)                                                                                          \
+#define MGX_W3(MM, SS, UU, OO, Y, WP, BP)                                                                           \
     do {                                                                                                            \
         static bool allowed = false;                                                                                \
         if (!allowed) {                                                                                             \
-            (void)hipFuncSetAttribute((const void*)wino3_kernel<MM, SS, UU>,                                        \
+            (void)hipFuncSetAttribute((const void*)wino3_kernel<MM, SS, UU, OO>,                                    \
                                       hipFuncAttributeMaxDynamicSharedMemorySize, W_LDS_BYTES);                     \
             allowed = true;                                                                                         \
         }                                                                                                           \
-        hipLaunchKernelGGL((wino3_kernel<MM, SS, UU>), dim3(grid), dim3(256), W_LDS_BYTES, st, d, x, xmul, w, bias, \
-                           y, dact, ntiles, tiles_h, tiles_w);                                                      \
+        hipLaunchKernelGGL((wino3_kernel<MM, SS, UU, OO>), dim3(grid), dim3(256), W_LDS_BYTES, st, d, x, xmul, WP,  \
+                           BP, Y, dact, ntiles, tiles_h, tiles_w);                                                  \
     } while (0)
 #define MGX_W3S(MM)                                                                                                 \
     do {                                                                                                            \
-        if (S16 == 2) MGX_W3(MM, 2, false);                                                                         \
-        else if (S16 == 4) MGX_W3(MM, 4, false);                                                                    \
-        else if (S16 == 6) MGX_W3(MM, 6, false);                                                                    \
-        else MGX_W3(MM, 8, false);                                                                                  \
+        if (S16 == 2) MGX_W3(MM, 2, false, 32, y, w, bias);                                                         \
+        else if (S16 == 4) MGX_W3(MM, 4, false, 32, y, w, bias);                                                    \
+        else if (S16 == 6) MGX_W3(MM, 6, false, 32, y, w, bias);                                                    \
+        else MGX_W3(MM, 8, false, 32, y, w, bias);                                                                  \
     } while (0)
     const int S16 = d.cin / 16;
     const bool act = d.act_alpha > 0.f;
-    if (xmul) MGX_W3(0, 2, true);
+    if (xmul && d.ngemm == 128) {
+        // four launches of 32 output channels: channel n of the filter lies n * wsn floats on
+        for (int nb = 0; nb < 4; ++nb)
+            MGX_W3(0, 2, true, 128, y + nb * 32, w + (long)nb * 32 * d.wsn, d.nbias ? bias + nb * 32 : bias);
+    } else if (xmul) MGX_W3(0, 2, true, 32, y, w, bias);
     else if (act && dact) MGX_W3S(2);
     else if (act) MGX_W3S(1);
     else MGX_W3S(0);
