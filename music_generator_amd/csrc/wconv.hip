@@ -120,8 +120,9 @@ struct WTile {
 // S16 = cin / 16 accumulation steps per tile (unrolled: the 16 accumulator tiles must not be
 // carried around a rolled loop; S16 is even, so the buffer of a step is a compile-time constant).
 // MUL: the input is x * xmul elementwise (data-gradients: dy times the saved activation derivative).
-// OSTR: floats between output positions (a launch computes 32 of the OSTR output channels; y, w and
-// bias arrive offset to the launch's first channel).
+// OSTR: output channels = floats between output positions.  With more than 32 the workgroup computes
+// them 32 at a time from the one staged input tile (both 16-channel slices stay in their LDS
+// buffers), the filter streaming through LDS one (channel block, slice) ahead.
 template <int MODE, int S16, bool MUL, int OSTR>
 __global__ __launch_bounds__(256, 1) void wino3_kernel(mgx_conv_desc d, const float* __restrict__ x,
                                                        const float* __restrict__ xmul,
@@ -132,7 +133,8 @@ __global__ __launch_bounds__(256, 1) void wino3_kernel(mgx_conv_desc d, const fl
     extern __shared__ __attribute__((aligned(16))) float lds[];
     float* ul = lds;                      // [2][16][4][32][4]
     float* xt = lds + 2 * W_USLICE;       // [2][WIH][W_RS][16]
-    constexpr bool kResidentU = S16 == 2;
+    constexpr int NB = OSTR / 32;         // output channel blocks
+    constexpr bool kResidentU = S16 == 2 && NB == 1;
     const int tid = threadIdx.x;
     const int lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 31, h = lane >> 5;
@@ -148,8 +150,10 @@ __global__ __launch_bounds__(256, 1) void wino3_kernel(mgx_conv_desc d, const fl
     const unsigned uvoff = (unsigned)(((ukq * 4 + 2 * uhalf) * d.wsk + un * d.wsn) * 4);
     const unsigned uvoff1 = uvoff + (unsigned)(d.wsk * 4);
     float* const ustore = ul + ukq * 128 + un * 4 + 2 * uhalf;
+    // filter slice u = output channel block u / S16, input channel slice u % S16
     auto u_load_tap = [&](int slice, int tap, f32x2 (&g)[9]) {
-        const int soff = (((d.flip ? 8 - tap : tap) * (int)d.wtap) + slice * 16 * d.wsk) * 4;
+        const int soff = (((d.flip ? 8 - tap : tap) * (int)d.wtap) + (slice % S16) * 16 * d.wsk +
+                          (slice / S16) * 32 * d.wsn) * 4;
         g[tap][0] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rw, uvoff, soff, 0));
         g[tap][1] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(rw, uvoff1, soff, 0));
     };
@@ -307,11 +311,15 @@ __global__ __launch_bounds__(256, 1) void wino3_kernel(mgx_conv_desc d, const fl
         // compiler's own choice moves a 256-register accumulator set into vector registers as soon
         // as a loop carries it or the unrolled code grows.  The first MFMA of a tile takes 0 as C.
         f32x16 acc[16];
-        auto step = [&](const int k16, const int k2, const bool first, const bool last) __attribute__((always_inline)) {
+        auto step = [&](const int k16, const int k2, const bool first, const bool last, const int nb)
+                        __attribute__((always_inline)) {
             const int buf = k2, ubuf = k2;
-            const int kn = last ? 0 : k16 + 1;
+            const int kn = NB == 1 ? (last ? 0 : k16 + 1) : (nb * S16 + k16 + 1) % (NB * S16);   // next filter slice
             // the tile and filter slice of the next step go into the buffers the previous step used
-            stage_prepare(last ? nxt : cur, kn, buf ^ 1, !last || next_tile);
+            // with several output blocks the input tile is staged during the first block only, the
+            // next tile's first slice during the last step of the last block
+            stage_prepare(last ? nxt : cur, last ? 0 : k16 + 1, buf ^ 1,
+                          NB == 1 ? (!last || next_tile) : (last ? (nb == NB - 1 && next_tile) : nb == 0));
             f32x2 g[9];
             // ---- 8 blocks (2 channel blocks x 4 row combinations) of 16 MFMAs, software-pipelined:
             //      while block b multiplies, the fragment of block b+1 is transformed in four slices
@@ -417,7 +425,7 @@ __global__ __launch_bounds__(256, 1) void wino3_kernel(mgx_conv_desc d, const fl
                 asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 7" ::: "memory");
                 if (h0 + 4 * wv < H) {                     // H is a multiple of 4: a wave is all in or all out
                     const unsigned vbase = (unsigned)(((w0 + 8 * h) * OSTR + r) * 4);
-                    const float bv = d.nbias > 0 ? bias[r] : 0.f;
+                    const float bv = d.nbias > 0 ? bias[nb * 32 + r] : 0.f;
                     const f32x2 bv2 = {bv, bv}, ia2 = {inv_alpha, inv_alpha};
                     // Output transform Y[a][b] = sum over (xi, nu) of At[a][xi] At[b][nu] M[xi][nu] with
                     // At = [1 1 1 0; 0 1 -1 -1]: every accumulator tile is copied out of the accumulation
@@ -448,7 +456,7 @@ __global__ __launch_bounds__(256, 1) void wino3_kernel(mgx_conv_desc d, const fl
                     for (int a = 0; a < 2; ++a) {
 #pragma unroll
                         for (int trs = 0; trs < 2; ++trs) {                         // patch row of registers 8 trs ..
-                            const long rowoff = (((long)cur.img * H + h0 + 4 * wv + 2 * trs + a) * (long)W) * OSTR;
+                            const long rowoff = (((long)cur.img * H + h0 + 4 * wv + 2 * trs + a) * (long)W) * OSTR + nb * 32;
                             const __amdgpu_buffer_rsrc_t ry =
                                 __builtin_amdgcn_make_buffer_rsrc((void*)(y + rowoff), 0, out_row_bytes, 0x00020000);
                             const __amdgpu_buffer_rsrc_t rd = __builtin_amdgcn_make_buffer_rsrc(
@@ -503,18 +511,24 @@ __global__ __launch_bounds__(256, 1) void wino3_kernel(mgx_conv_desc d, const fl
             __builtin_amdgcn_s_barrier();
             asm volatile("" ::: "memory");
         };
-        if (S16 <= 4) {
+        if (NB > 1) {
+#pragma unroll 1
+            for (int nb = 0; nb < NB; ++nb) {
+                step(0, 0, true, false, nb);
+                step(1, 1, false, true, nb);
+            }
+        } else if (S16 <= 4) {
 #pragma unroll
-            for (int k16 = 0; k16 < S16; ++k16) step(k16, k16 & 1, k16 == 0, k16 + 1 == S16);
+            for (int k16 = 0; k16 < S16; ++k16) step(k16, k16 & 1, k16 == 0, k16 + 1 == S16, 0);
         } else {
             // more than two step pairs: the first pair apart (it starts the accumulators), the rest
             // a loop, which also keeps the code inside the instruction cache
-            step(0, 0, true, false);
-            step(1, 1, false, false);
+            step(0, 0, true, false, 0);
+            step(1, 1, false, false, 0);
 #pragma unroll 1
             for (int kk = 2; kk < S16; kk += 2) {
-                step(kk, 0, false, false);
-                step(kk + 1, 1, false, kk + 2 == S16);
+                step(kk, 0, false, false, 0);
+                step(kk + 1, 1, false, kk + 2 == S16, 0);
             }
         }
         t += gridDim.x;
@@ -526,7 +540,7 @@ __global__ __launch_bounds__(256, 1) void wino3_kernel(mgx_conv_desc d, const fl
 // 3x3 'same' convolutions that the Winograd kernel covers: 32 output channels in the forward layout
 // (weights [tap][k][n]) or the data-gradient layout ([tap][n][k], flipped taps); with an input
 // multiplier (the data-gradients of the discriminator blocks: 32 input channels, no activation) also
-// 64..128 output channels, computed 32 at a time by one launch each.
+// 128 output channels, computed 32 at a time from one staged input tile.
 bool mgx_wconv_applicable(const mgx_conv_desc& d, bool mul) {
     if (d.kh != 3 || d.kw != 3 || d.sh != 1 || d.sw != 1 || d.dkh != 1 || d.dkw != 1) return false;
     if (d.pt != 1 || d.pl != 1 || d.hout != d.hin || d.wout != d.win || d.accumulate) return false;
@@ -567,11 +581,8 @@ int mgx_wconv_launch(const mgx_conv_desc& d, const float* x, const float* xmul, 
     } while (0)
     const int S16 = d.cin / 16;
     const bool act = d.act_alpha > 0.f;
-    if (xmul && d.ngemm == 128) {
-        // four launches of 32 output channels: channel n of the filter lies n * wsn floats on
-        for (int nb = 0; nb < 4; ++nb)
-            MGX_W3(0, 2, true, 128, y + nb * 32, w + (long)nb * 32 * d.wsn, d.nbias ? bias + nb * 32 : bias);
-    } else if (xmul) MGX_W3(0, 2, true, 32, y, w, bias);
+    if (xmul && d.ngemm == 128) MGX_W3(0, 2, true, 128, y, w, bias);
+    else if (xmul) MGX_W3(0, 2, true, 32, y, w, bias);
     else if (act && dact) MGX_W3S(2);
     else if (act) MGX_W3S(1);
     else MGX_W3S(0);
