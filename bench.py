@@ -163,7 +163,7 @@ def main():
                 "share_of_step_time": round(ms / args.steps / ms_per_step, 3),
                 "all_contractions_share_of_step_time": round(contraction_ms / args.steps / ms_per_step, 3),
                 "step_tflops_algorithmic": round(STEP_GFLOP_PER_SAMPLE[stage] * args.batch / ms_per_step, 2)}
-    if key == "wino3_kernel":
+    if key.startswith("wino3_"):
         # the kernel's algorithm is Winograd F(2x2,3x3): `achieved` counts the multiply-adds it executes
         # (16 per 2x2 patch and channel pair); the same launches as a rate of direct-convolution FLOPs:
         roofline["direct_convolution_equivalent_tflops"] = round(achieved / ops.WINOGRAD_FLOP_FRACTION, 2)

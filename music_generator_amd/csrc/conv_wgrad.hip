@@ -11,6 +11,13 @@
 #include "../../include/mgx.h"
 
 bool mgx_twgrad_applicable(const mgx_conv_desc& d);
+bool mgx_wconv_enabled();                                   // conv_gemm.hip
+bool mgx_wwgrad_applicable(const mgx_conv_desc& d);         // wwgrad.hip
+long mgx_wwgrad_splits(const mgx_conv_desc& d);
+long mgx_wwgrad_du_floats(const mgx_conv_desc& d);
+int mgx_wwgrad_launch(const mgx_conv_desc& d, const float* x, const float* dy, const float* dymul, float* partial,
+                      float* bpartial, hipStream_t st);
+int mgx_wwgrad_finish(const mgx_conv_desc& d, const float* du, float* dw, hipStream_t st);
 long mgx_twgrad_splits(const mgx_conv_desc& d);
 int mgx_twgrad_launch(const mgx_conv_desc& d, const float* x, const float* dy, const float* dymul, float* partial,
                       float* bpartial, hipStream_t st);
@@ -26,6 +33,8 @@ struct WgradPlan {
     long tiles_total;
     long partial_floats, bias_floats;
     bool tiled;             // LDS-staged tile kernel (tconv.hip)
+    bool wino;              // Winograd kernel (wwgrad.hip): 16 transform-domain tiles per 32-channel slice
+    long du_floats;         // its transform-domain gradient between slab reduction and final transform
 };
 
 WgradPlan make_plan(const mgx_conv_desc& d) {
@@ -41,6 +50,20 @@ WgradPlan make_plan(const mgx_conv_desc& d) {
     else {
         p.KT = p.ktot >= 2 ? 2 : 1;
         p.NT = p.ntot >= 4 ? 4 : (p.ntot >= 2 ? 2 : 1);
+    }
+    p.wino = mgx_wconv_enabled() && mgx_wwgrad_applicable(d);
+    p.du_floats = 0;
+    if (p.wino) {
+        p.tiled = false;
+        p.T = 16; p.KT = 1; p.NT = 1;
+        p.tap_groups = 1; p.k_groups = p.ktot; p.n_groups = 1;
+        p.splits = mgx_wwgrad_splits(d);
+        p.rows_per_split = 0;
+        p.tiles_total = 16L * p.ktot;
+        p.partial_floats = p.splits * p.tiles_total * 1024;
+        p.bias_floats = p.splits * 64;
+        p.du_floats = mgx_wwgrad_du_floats(d);
+        return p;
     }
     p.tiled = mgx_twgrad_applicable(d);
     if (p.tiled) {
@@ -336,7 +359,7 @@ extern "C" int64_t mgx_conv_wgrad_workspace(const mgx_conv_desc* dp) {
     if (pointwise2_wgrad_applicable(*dp))
         return (int64_t)pointwise2_wgrad_plan(*dp).blocks * 3 * dp->ngemm * (int64_t)sizeof(float);
     const WgradPlan p = make_plan(*dp);
-    return (p.partial_floats + p.bias_floats) * (int64_t)sizeof(float);
+    return (p.partial_floats + p.bias_floats + p.du_floats) * (int64_t)sizeof(float);
 }
 
 extern "C" int mgx_conv_wgrad_f32(const mgx_conv_desc* dp, const float* x, const float* dy, const float* dymul,
@@ -363,10 +386,30 @@ extern "C" int mgx_conv_wgrad_f32(const mgx_conv_desc* dp, const float* x, const
         return mgx_launch_status();
     }
     const WgradPlan p = make_plan(d);
-    if ((p.partial_floats + p.bias_floats) * (int64_t)sizeof(float) > workspace_bytes) return MGX_ERR_WORKSPACE;
+    if ((p.partial_floats + p.bias_floats + p.du_floats) * (int64_t)sizeof(float) > workspace_bytes)
+        return MGX_ERR_WORKSPACE;
     hipStream_t st = (hipStream_t)stream;
     float* partial = (float*)workspace;
     float* bpartial = dbias ? partial + p.partial_floats : nullptr;
+    if (p.wino) {
+        // slabs -> dU[16][cin][32] (the generic fixed-order slab reduction with the 16 transform
+        // positions in the place of taps) -> dw += G^T dU G
+        float* du = partial + p.partial_floats + p.bias_floats;
+        if (mgx_wwgrad_launch(d, x, dy, dymul, partial, bpartial, st) != MGX_OK) return MGX_ERR_LAUNCH;
+        if (hipMemsetAsync(du, 0, p.du_floats * sizeof(float), st) != hipSuccess) return MGX_ERR_LAUNCH;
+        mgx_conv_desc du_desc = d;
+        du_desc.kh = du_desc.kw = 4;
+        du_desc.wtap = (int64_t)d.cin * 32;
+        du_desc.wsk = 32;
+        du_desc.wsn = 1;
+        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((p.du_floats + 63) / 64)), dim3(1024), 0, st, du_desc,
+                           partial, du, p.splits, p.ktot, p.ntot, p.tiles_total);
+        if (mgx_wwgrad_finish(d, du, dw, st) != MGX_OK) return MGX_ERR_LAUNCH;
+        if (dbias)
+            hipLaunchKernelGGL(bias_reduce_kernel, dim3((unsigned)d.nbias), dim3(256), 0, st, d, bpartial, dbias,
+                               p.splits, p.ntot);
+        return mgx_launch_status();
+    }
 #define MGX_WG(TT, KK, NN) launch_wgrad<TT, KK, NN>(d, p, x, dy, dymul, partial, bpartial, st)
     if (p.tiled) {
         if (mgx_twgrad_launch(d, x, dy, dymul, partial, bpartial, st) != MGX_OK) return MGX_ERR_LAUNCH;

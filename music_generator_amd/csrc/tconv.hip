@@ -206,10 +206,14 @@ bool mgx_twgrad_applicable(const mgx_conv_desc& d) {
 bool mgx_pointwise2_applicable(const mgx_conv_desc& d);   // conv_gemm.hip
 bool mgx_wconv_enabled();                                  // conv_gemm.hip
 bool mgx_wconv_applicable(const mgx_conv_desc& d, bool mul);   // wconv.hip
+bool mgx_wwgrad_applicable(const mgx_conv_desc& d);            // wwgrad.hip
 
 extern "C" int mgx_conv_route(const mgx_conv_desc* d, int wgrad) {
     if (!d) return 0;
-    if (wgrad == 1) return mgx_twgrad_applicable(*d) ? 1 : (mgx_pointwise2_applicable(*d) ? 2 : 0);
+    if (wgrad == 1) {
+        if (mgx_wconv_enabled() && mgx_wwgrad_applicable(*d)) return 3;
+        return mgx_twgrad_applicable(*d) ? 1 : (mgx_pointwise2_applicable(*d) ? 2 : 0);
+    }
     if (mgx_wconv_enabled() && mgx_wconv_applicable(*d, wgrad == 2)) return 3;
     if (mgx_tconv_applicable(*d)) return 1;
     return mgx_pointwise2_applicable(*d) ? 2 : 0;

@@ -94,6 +94,8 @@ def _gemm_key(d: ConvDesc, mul: bool = False) -> str:
 
 def _wgrad_key(d: ConvDesc) -> str:
     route = _lib().mgx_conv_route(C.byref(d), 1)
+    if route == 3:
+        return "wino3_wgrad_kernel"
     if route == 2:
         return "pointwise2_wgrad_kernel"
     if route == 1:
@@ -119,7 +121,7 @@ WINOGRAD_FLOP_FRACTION = 16.0 / 36.0
 def _gemm_flops(d: ConvDesc, key: str) -> float:
     """FLOPs of the algorithm the launch runs: the direct contraction, or for the Winograd
     F(2x2,3x3) kernel its 16 multiply-adds per 2x2 output patch and channel pair in place of 36."""
-    return _conv_flops(d) * (WINOGRAD_FLOP_FRACTION if key == "wino3_kernel" else 1.0)
+    return _conv_flops(d) * (WINOGRAD_FLOP_FRACTION if key.startswith("wino3_") else 1.0)
 
 
 def _conv_bytes(d: ConvDesc, n_in: int = 1, n_out: int = 1) -> float:
@@ -186,7 +188,8 @@ def conv_wgrad(d: ConvDesc, x, dy, dw, dbias, dymul=None):
     check(lib.mgx_conv_wgrad_f32(C.byref(d), _p(x), _p(dy), _p(dymul), _p(dw), _p(dbias),
                                  ws.data_ptr(), ws.numel(), K.stream_ptr()), "mgx_conv_wgrad_f32")
     if e0 is not None:
-        PROFILER.stop(_wgrad_key(d), _conv_flops(d), e0, _conv_bytes(d, 1, 2 if dymul is not None else 1))
+        key = _wgrad_key(d)
+        PROFILER.stop(key, _gemm_flops(d, key), e0, _conv_bytes(d, 1, 2 if dymul is not None else 1))
 
 
 def gblock_pack_floats() -> int:

@@ -236,9 +236,10 @@ def test_cabi_rejects_bad_arguments_before_touching_the_device():
     assert need > 0
     assert lib.mgx_conv_wgrad_f32(ctypes.byref(d), fake, fake, None, fake, fake, fake, need - 1, None) \
         == _cabi.MGX_ERR_WORKSPACE
-    # forward: Winograd kernel (tile kernel when switched off), weight gradient: tile kernel
-    assert lib.mgx_conv_route(ctypes.byref(d), 0) == (3 if os.environ.get("MGX_WINOGRAD", "1") != "0" else 1)
-    assert lib.mgx_conv_route(ctypes.byref(d), 1) == 1
+    # forward and weight gradient: Winograd kernels (tile kernels when switched off)
+    wino = 3 if os.environ.get("MGX_WINOGRAD", "1") != "0" else 1
+    assert lib.mgx_conv_route(ctypes.byref(d), 0) == wino and lib.mgx_conv_route(ctypes.byref(d), 1) == wino
+    assert lib.mgx_conv_route(ctypes.byref(d), 2) == wino          # with an input multiplier: 32 channels, linear
     d.hin = d.hout = 4                                   # not a multiple of the 8-row tile
     assert lib.mgx_conv_route(ctypes.byref(d), 0) == 0
     # fused generator block: unset weight pointers, misaligned range, short workspace
