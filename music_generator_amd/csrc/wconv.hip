@@ -479,6 +479,8 @@ bool mgx_wconv_applicable(const mgx_conv_desc& d, bool mul) {
     if (d.kh != 3 || d.kw != 3 || d.sh != 1 || d.sw != 1 || d.dkh != 1 || d.dkw != 1) return false;
     if (d.pt != 1 || d.pl != 1 || d.hout != d.hin || d.wout != d.win || d.accumulate) return false;
     if (d.hin % 4 || d.hin < 8 || d.cin % 32 || d.cin < 32 || d.cin > 128 || d.cout != d.ngemm) return false;
+    // 8 rows fill half of a 16-row tile: with 32 input channels the direct 8-row tile kernel is faster there
+    if (d.hin < 16 && d.cin == 32) return false;
     if (mul) {
         if (d.cin != 32 || d.act_alpha > 0.f || (d.ngemm != 32 && d.ngemm != 128)) return false;
     } else if (d.ngemm != 32) return false;

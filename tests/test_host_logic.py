@@ -222,7 +222,7 @@ def test_cabi_rejects_bad_arguments_before_touching_the_device():
     the documented status codes (no GPU needed to observe them)."""
     lib = _cabi.load()
     d = _cabi.ConvDesc()
-    for k, v in dict(nimg=1, hin=8, win=32, cin=32, hout=8, wout=32, kh=3, kw=3, sh=1, sw=1, pt=1, pl=1, flip=0,
+    for k, v in dict(nimg=1, hin=16, win=32, cin=32, hout=16, wout=32, kh=3, kw=3, sh=1, sw=1, pt=1, pl=1, flip=0,
                      ngemm=32, dkh=1, dkw=1, cout=32, wsk=32, wsn=1, wtap=1024, nbias=32, accumulate=0).items():
         setattr(d, k, v)
     d.act_alpha = 0.0
