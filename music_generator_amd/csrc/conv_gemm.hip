@@ -76,66 +76,90 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(mgx_conv_desc d, const f
         nok[nt] = ncol[nt] < d.ngemm;
     }
 
-    for (int a = 0; a < d.kh; ++a) {
-        for (int b = 0; b < d.kw; ++b) {
-            const int wt = d.flip ? ((d.kh - 1 - a) * d.kw + (d.kw - 1 - b)) : (a * d.kw + b);
-            const float* wtap = w + (long)wt * d.wtap;
-            bool ok[PT];
-            long xoff[PT];
+    // One flat loop over (tap, 8-channel step) with the operands of the next step loaded before the
+    // MFMAs of the current one: the loads are per-lane gathers straight from global memory, their
+    // latency must not sit between every two groups of MFMAs.
+    const int ksteps = (d.cin + 7) / 8;
+    const int total = d.kh * d.kw * ksteps;
+    int ta = 0, tb = 0, tk = 0;                 // tap and channel step of the next load
+    const float* wtap = w;
+    bool ok[PT];
+    long xoff[PT];
+    auto tap_state = [&]() {
+        const int wt = d.flip ? ((d.kh - 1 - ta) * d.kw + (d.kw - 1 - tb)) : (ta * d.kw + tb);
+        wtap = w + (long)wt * d.wtap;
 #pragma unroll
-            for (int pt = 0; pt < PT; ++pt) {
-                const int hi = ho[pt] * d.sh + a - d.pt;
-                const int wi = wo[pt] * d.sw + b - d.pl;
-                ok[pt] = valid[pt] && hi >= 0 && hi < d.hin && wi >= 0 && wi < d.win;
-                xoff[pt] = ((img[pt] * d.hin + hi) * d.win + wi) * (long)d.cin;
+        for (int pt = 0; pt < PT; ++pt) {
+            const int hi = ho[pt] * d.sh + ta - d.pt;
+            const int wi = wo[pt] * d.sw + tb - d.pl;
+            ok[pt] = valid[pt] && hi >= 0 && hi < d.hin && wi >= 0 && wi < d.win;
+            xoff[pt] = ((img[pt] * d.hin + hi) * d.win + wi) * (long)d.cin;
+        }
+    };
+    auto load = [&](f32x4 (&xa)[PT], f32x4 (&wb)[NT]) {
+        const int kk = tk * 8 + 4 * h;
+#pragma unroll
+        for (int pt = 0; pt < PT; ++pt) {
+            xa[pt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if (ok[pt]) {
+                if (KVEC) {
+                    xa[pt] = *(const f32x4*)(x + xoff[pt] + kk);
+                    if (xmul) xa[pt] *= *(const f32x4*)(xmul + xoff[pt] + kk);
+                } else {
+#pragma unroll
+                    for (int j = 0; j < 4; ++j)
+                        if (kk + j < d.cin) {
+                            float v = x[xoff[pt] + kk + j];
+                            if (xmul) v *= xmul[xoff[pt] + kk + j];
+                            xa[pt][j] = v;
+                        }
+                }
             }
-            for (int k0 = 0; k0 < d.cin; k0 += 8) {
-                const int kk = k0 + 4 * h;
-                f32x4 xa[PT];
+        }
 #pragma unroll
-                for (int pt = 0; pt < PT; ++pt) {
-                    xa[pt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-                    if (ok[pt]) {
-                        if (KVEC) {
-                            xa[pt] = *(const f32x4*)(x + xoff[pt] + kk);
-                            if (xmul) xa[pt] *= *(const f32x4*)(xmul + xoff[pt] + kk);
-                        } else {
+        for (int nt = 0; nt < NT; ++nt) {
+            wb[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if (nok[nt]) {
+                if (WMODE == 0) {
 #pragma unroll
-                            for (int j = 0; j < 4; ++j)
-                                if (kk + j < d.cin) {
-                                    float v = x[xoff[pt] + kk + j];
-                                    if (xmul) v *= xmul[xoff[pt] + kk + j];
-                                    xa[pt][j] = v;
-                                }
-                        }
+                    for (int j = 0; j < 4; ++j)
+                        if (KVEC || kk + j < d.cin) wb[nt][j] = wtap[(long)(kk + j) * d.wsk + ncol[nt]];
+                } else {
+                    if (KVEC) {
+                        wb[nt] = *(const f32x4*)(wtap + (long)ncol[nt] * d.wsn + kk);
+                    } else {
+#pragma unroll
+                        for (int j = 0; j < 4; ++j)
+                            if (kk + j < d.cin) wb[nt][j] = wtap[(long)ncol[nt] * d.wsn + kk + j];
                     }
                 }
-                f32x4 wb[NT];
+            }
+        }
+        // advance to the step after this one
+        if (++tk == ksteps) {
+            tk = 0;
+            if (++tb == d.kw) tb = 0, ++ta;
+            if (ta < d.kh) tap_state();
+        }
+    };
+    auto mma = [&](const f32x4 (&xa)[PT], const f32x4 (&wb)[NT]) {
 #pragma unroll
-                for (int nt = 0; nt < NT; ++nt) {
-                    wb[nt] = (f32x4){0.f, 0.f, 0.f, 0.f};
-                    if (nok[nt]) {
-                        if (WMODE == 0) {
+        for (int j = 0; j < 4; ++j)
 #pragma unroll
-                            for (int j = 0; j < 4; ++j)
-                                if (KVEC || kk + j < d.cin) wb[nt][j] = wtap[(long)(kk + j) * d.wsk + ncol[nt]];
-                        } else {
-                            if (KVEC) {
-                                wb[nt] = *(const f32x4*)(wtap + (long)ncol[nt] * d.wsn + kk);
-                            } else {
+            for (int pt = 0; pt < PT; ++pt)
 #pragma unroll
-                                for (int j = 0; j < 4; ++j)
-                                    if (kk + j < d.cin) wb[nt][j] = wtap[(long)ncol[nt] * d.wsn + kk + j];
-                            }
-                        }
-                    }
-                }
-#pragma unroll
-                for (int j = 0; j < 4; ++j)
-#pragma unroll
-                    for (int pt = 0; pt < PT; ++pt)
-#pragma unroll
-                        for (int nt = 0; nt < NT; ++nt) acc[pt][nt] = mfma32(xa[pt][j], wb[nt][j], acc[pt][nt]);
+                for (int nt = 0; nt < NT; ++nt) acc[pt][nt] = mfma32(xa[pt][j], wb[nt][j], acc[pt][nt]);
+    };
+    {
+        f32x4 xa0[PT], wb0[NT], xa1[PT], wb1[NT];
+        tap_state();
+        load(xa0, wb0);
+        for (int s = 0; s < total; s += 2) {
+            if (s + 1 < total) load(xa1, wb1);
+            mma(xa0, wb0);
+            if (s + 1 < total) {
+                if (s + 2 < total) load(xa0, wb0);
+                mma(xa1, wb1);
             }
         }
     }
