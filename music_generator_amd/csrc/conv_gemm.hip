@@ -327,6 +327,74 @@ int launch_pointwise2(const mgx_conv_desc& d, const float* x, const float* w, co
 
 bool mgx_pointwise2_applicable(const mgx_conv_desc& d) { return pointwise2_applicable(d, nullptr); }
 
+namespace {
+
+// 1x1 convolution to 2 output channels (the data-gradient of the from-audio layers): two dot
+// products per position over C = 4 q input channels, read once at the HBM rate.  q lanes share a
+// position (16 bytes each, optionally times the multiplier), reduce with shuffles, lane 0 stores.
+template <bool MUL>
+__global__ __launch_bounds__(256) void pointwise_to2_kernel(const float* __restrict__ x,
+                                                            const float* __restrict__ xmul,
+                                                            const float* __restrict__ w, const float* __restrict__ bias,
+                                                            float* __restrict__ y, long npos, int cin, int wsk, int wsn,
+                                                            int nbias, int pos_per_block) {
+    const int q = cin >> 2;                       // lanes per position: a power of two <= 64
+    const int c = (threadIdx.x % q) * 4, pl = threadIdx.x / q, pstep = 256 / q;
+    f32x4 w0, w1;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+        w0[j] = w[(long)(c + j) * wsk];
+        w1[j] = w[(long)(c + j) * wsk + wsn];
+    }
+    const float b0 = nbias > 0 ? bias[0] : 0.f, b1 = nbias > 0 ? bias[1 % nbias] : 0.f;
+    const long p0 = (long)blockIdx.x * pos_per_block;
+    const long p1 = p0 + pos_per_block < npos ? p0 + pos_per_block : npos;
+    const long span = p1 - p0;
+    // every lane runs the same number of iterations (the shuffles need all lanes of a group)
+    for (long i = pl; i < ((span + pstep - 1) / pstep) * pstep; i += pstep) {
+        const long p = p0 + i;
+        const bool ok = i < span;
+        f32x4 v = (f32x4){0.f, 0.f, 0.f, 0.f};
+        if (ok) {
+            v = __builtin_nontemporal_load((const f32x4*)(x + p * cin + c));
+            if (MUL) v *= __builtin_nontemporal_load((const f32x4*)(xmul + p * cin + c));
+        }
+        float s0 = v[0] * w0[0] + v[1] * w0[1] + v[2] * w0[2] + v[3] * w0[3];
+        float s1 = v[0] * w1[0] + v[1] * w1[1] + v[2] * w1[2] + v[3] * w1[3];
+        for (int o = q >> 1; o > 0; o >>= 1) {
+            s0 += __shfl_xor(s0, o, 64);
+            s1 += __shfl_xor(s1, o, 64);
+        }
+        if (ok && c == 0) *(float2*)(y + p * 2) = make_float2(s0 + b0, s1 + b1);
+    }
+}
+
+bool pointwise_to2_applicable(const mgx_conv_desc& d) {
+    const int q = d.cin / 4;
+    return d.kh == 1 && d.kw == 1 && d.sh == 1 && d.sw == 1 && d.dkh == 1 && d.dkw == 1 && d.pt == 0 && d.pl == 0 &&
+           d.hout == d.hin && d.wout == d.win && d.ngemm == 2 && d.cout == 2 && d.cin % 4 == 0 && q >= 1 && q <= 64 &&
+           (q & (q - 1)) == 0 && d.act_alpha <= 0.f && !d.accumulate && (d.nbias == 0 || d.nbias == 2);
+}
+
+int launch_pointwise_to2(const mgx_conv_desc& d, const float* x, const float* xmul, const float* w, const float* bias,
+                         float* y, hipStream_t st) {
+    const long npos = (long)d.nimg * d.hin * d.win;
+    const int ppb = 512;
+    dim3 grid((unsigned)((npos + ppb - 1) / ppb)), block(256);
+    if (xmul)
+        hipLaunchKernelGGL((pointwise_to2_kernel<true>), grid, block, 0, st, x, xmul, w, bias, y, npos, d.cin, d.wsk,
+                           d.wsn, d.nbias, ppb);
+    else
+        hipLaunchKernelGGL((pointwise_to2_kernel<false>), grid, block, 0, st, x, xmul, w, bias, y, npos, d.cin, d.wsk,
+                           d.wsn, d.nbias, ppb);
+    return mgx_launch_status();
+}
+
+}  // namespace
+
+// route 2 also covers the 1x1 convolutions to 2 output channels (any input multiplier)
+bool mgx_pointwise_to2_applicable(const mgx_conv_desc& d) { return pointwise_to2_applicable(d); }
+
 // The Winograd forward kernel is used unless the environment says MGX_WINOGRAD=0 (read once).
 // read at every call: a process can compare the two kernels on the same operands
 bool mgx_wconv_enabled() {
@@ -350,6 +418,7 @@ extern "C" int mgx_conv_gemm_f32(const mgx_conv_desc* dp, const float* x, const 
         return mgx_wconv_launch(d, x, xmul, w, bias, y, dact, st);
     if (mgx_tconv_applicable(d)) return mgx_tconv_launch(d, x, xmul, w, bias, y, dact, st);
     if (pointwise2_applicable(d, xmul)) return launch_pointwise2(d, x, w, bias, y, dact, st);
+    if (pointwise_to2_applicable(d) && !dact) return launch_pointwise_to2(d, x, xmul, w, bias, y, st);
     const int ntiles = (d.ngemm + 31) / 32;
     if (ntiles == 1) return launch_pn<4, 1>(d, x, xmul, w, bias, y, dact, st);
     if (ntiles == 2) return launch_pn<2, 2>(d, x, xmul, w, bias, y, dact, st);

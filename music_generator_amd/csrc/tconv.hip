@@ -204,6 +204,7 @@ bool mgx_twgrad_applicable(const mgx_conv_desc& d) {
 }
 
 bool mgx_pointwise2_applicable(const mgx_conv_desc& d);   // conv_gemm.hip
+bool mgx_pointwise_to2_applicable(const mgx_conv_desc& d);
 bool mgx_wconv_enabled();                                  // conv_gemm.hip
 bool mgx_wconv_applicable(const mgx_conv_desc& d, bool mul);   // wconv.hip
 bool mgx_wwgrad_applicable(const mgx_conv_desc& d);            // wwgrad.hip
@@ -216,7 +217,8 @@ extern "C" int mgx_conv_route(const mgx_conv_desc* d, int wgrad) {
     }
     if (mgx_wconv_enabled() && mgx_wconv_applicable(*d, wgrad == 2)) return 3;
     if (mgx_tconv_applicable(*d)) return 1;
-    return mgx_pointwise2_applicable(*d) ? 2 : 0;
+    if (mgx_pointwise_to2_applicable(*d)) return 2;
+    return mgx_pointwise2_applicable(*d) && wgrad == 0 ? 2 : 0;
 }
 
 long mgx_twgrad_splits(const mgx_conv_desc& d) {

@@ -80,8 +80,8 @@ def _hbm_op(name):
 
 def _gemm_key(d: ConvDesc, mul: bool = False) -> str:
     route = _lib().mgx_conv_route(C.byref(d), 2 if mul else 0)
-    if route == 2 and not mul:
-        return "pointwise2_kernel"
+    if route == 2:
+        return "pointwise_to2_kernel" if d.ngemm == 2 else "pointwise2_kernel"
     if route == 3:
         return "wino3_kernel"
     if route == 1:

@@ -262,7 +262,7 @@ def test_micro_batching_reproduces_whole_batch_step():
                                                      (2, True, 3, 48 << 20), (1, False, 1, 1 << 20)])
 def test_fused_generator_backward_matches_layerwise(stage, fade, batch, budget):
     """The fused grow-block kernels (saving forward, register-chained data gradient, tile-major
-    weight gradients) against the layer-by-layer taped path on the same device: output abs 2e-5,
+    weight gradients) against the layer-by-layer taped path on the same device: output abs 2e-5 x max|y|,
     every gradient tensor rel-L2 2e-5 (float32 summation order is the only difference).  Batch
     1 and 3 leave the last 32-position tile partly empty; with a side-buffer budget the backward
     re-computes the block's tensors over several position ranges."""
@@ -292,7 +292,7 @@ def test_fused_generator_backward_matches_layerwise(stage, fade, batch, budget):
         results.append((y.cpu().numpy(), dz.cpu().numpy(),
                         {v.name: v.grad.cpu().numpy().copy() for v in model.trainable_variables}))
     (y0, dz0, g0), (y1, dz1, g1) = results
-    assert np.abs(y0 - y1).max() < 2e-5
+    assert np.abs(y0 - y1).max() < 2e-5 * max(1.0, float(np.abs(y0).max()))
     assert rel_l2(dz1, dz0) < 2e-5
     for name, want in g0.items():
         if np.abs(want).max() < 1e-12:
