@@ -150,17 +150,18 @@ __global__ __launch_bounds__(256) void wgrad_kernel(mgx_conv_desc d, const float
     }
 
     if (rbeg < rend) {
-        // position of this lane's first row (rbeg + h), then advance by 2 rows per step
+        // position of this lane's first row (rbeg + h), then advance by 2 rows per step; the operands
+        // of the next step are loaded before the MFMAs of the current one (the loads are per-lane
+        // dwords straight from global memory: their latency must not sit between every two steps)
         long row = rbeg + h;
         const int hw = d.hout * d.wout;
         long img = row / hw;
         int rem = (int)(row - img * hw);
         int ho = rem / d.wout;
         int wo = rem - ho * d.wout;
-        for (; row - h < rend; row += 2) {
+        auto load = [&](float (&bv)[NT], float (&av)[T][KT]) {
             const bool rv = row < rend;
             const long ybase = ((img * d.hout + ho) * d.dkh * out_w + (long)wo * d.dkw) * d.cout;
-            float bv[NT];
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt) {
                 float v = 0.f;
@@ -169,7 +170,6 @@ __global__ __launch_bounds__(256) void wgrad_kernel(mgx_conv_desc d, const float
                     if (dymul) v *= dymul[ybase + npart[nt]];
                 }
                 bv[nt] = v;
-                bsum[nt] += v;
             }
 #pragma unroll
             for (int t = 0; t < T; ++t) {
@@ -179,17 +179,34 @@ __global__ __launch_bounds__(256) void wgrad_kernel(mgx_conv_desc d, const float
                 const int wi = wo * d.sw + b - d.pl;
                 const bool ok = rv && hi >= 0 && hi < d.hin && wi >= 0 && wi < d.win;
                 const long xoff = ((img * d.hin + hi) * d.win + wi) * (long)d.cin;
-                float av[KT];
 #pragma unroll
-                for (int kt = 0; kt < KT; ++kt) av[kt] = (ok && kok[kt]) ? x[xoff + kcol[kt]] : 0.f;
-#pragma unroll
-                for (int kt = 0; kt < KT; ++kt)
-#pragma unroll
-                    for (int nt = 0; nt < NT; ++nt) acc[t][kt][nt] = mfma32(av[kt], bv[nt], acc[t][kt][nt]);
+                for (int kt = 0; kt < KT; ++kt) av[t][kt] = (ok && kok[kt]) ? x[xoff + kcol[kt]] : 0.f;
             }
+            row += 2;
             wo += 2;
             while (wo >= d.wout) { wo -= d.wout; ++ho; }
             while (ho >= d.hout) { ho -= d.hout; ++img; }
+        };
+        auto mma = [&](const float (&bv)[NT], const float (&av)[T][KT]) {
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) bsum[nt] += bv[nt];
+#pragma unroll
+            for (int t = 0; t < T; ++t)
+#pragma unroll
+                for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+                    for (int nt = 0; nt < NT; ++nt) acc[t][kt][nt] = mfma32(av[t][kt], bv[nt], acc[t][kt][nt]);
+        };
+        const long steps = (rend - rbeg + 1) / 2;          // row pairs (the same for both lane halves)
+        float bv0[NT], av0[T][KT], bv1[NT], av1[T][KT];
+        load(bv0, av0);
+        for (long s2 = 0; s2 < steps; s2 += 2) {
+            if (s2 + 1 < steps) load(bv1, av1);
+            mma(bv0, av0);
+            if (s2 + 1 < steps) {
+                if (s2 + 2 < steps) load(bv0, av0);
+                mma(bv1, av1);
+            }
         }
     }
 
