@@ -169,7 +169,25 @@ int tile_grid(long ntiles) {
 }  // namespace
 
 // Is this contraction a stride-1 'same' conv the tile kernels cover?
+// the two strided forms the 1x1 tile kernel covers: 2x2 stride-2 'valid' convolution 32 -> 32 (input
+// gathered as a 128-channel position) and its data-gradient (1x1, 32 -> 4 x 32 with depth-to-space)
+static bool strided2_applicable(const mgx_conv_desc& d) {
+    if (d.nbias != 0 && d.nbias != d.ngemm && !(d.dkh == 2 && d.nbias == d.cout)) return false;
+    if ((long)2 * (TH + 2) * 2 * d.win * 32 * 4 >= (1L << 31)) return false;
+    if ((long)d.nimg * (d.hout / TH) * ((d.wout + TW - 1) / TW) >= (1L << 31)) return false;
+    if (d.kh == 2 && d.kw == 2 && d.sh == 2 && d.sw == 2 && d.dkh == 1 && d.dkw == 1 && d.pt == 0 && d.pl == 0 &&
+        d.flip == 0 && d.cin == 32 && d.ngemm == 32 && d.cout == 32 && d.hin == 2 * d.hout && d.win == 2 * d.wout &&
+        d.hout % TH == 0 && d.wsn == 1 && d.wsk == 32 && d.wtap == 1024)
+        return true;
+    if (d.kh == 1 && d.kw == 1 && d.sh == 1 && d.sw == 1 && d.dkh == 2 && d.dkw == 2 && d.pt == 0 && d.pl == 0 &&
+        d.cin == 32 && d.cout == 32 && d.ngemm == 128 && d.hout == d.hin && d.wout == d.win && d.hin % TH == 0 &&
+        d.nbias == 0 && ((d.wsk == 1 && d.wsn == 32) || (d.wsn == 1 && d.wsk == 128)))
+        return true;
+    return false;
+}
+
 bool mgx_tconv_applicable(const mgx_conv_desc& d) {
+    if (strided2_applicable(d)) return true;
     if (d.kh != d.kw || d.kh < 1 || d.kh > 3) return false;
     if (d.sh != 1 || d.sw != 1 || d.dkh != 1 || d.dkw != 1) return false;
     if (d.hout != d.hin || d.wout != d.win) return false;
@@ -200,7 +218,7 @@ int mgx_tconv_launch(const mgx_conv_desc& d, const float* x, const float* xmul, 
 
 // weight gradient: same applicability on the FORWARD descriptor, output channels must be 32
 bool mgx_twgrad_applicable(const mgx_conv_desc& d) {
-    return mgx_tconv_applicable(d) && d.kh >= 2 && d.ngemm == 32 && d.flip == 0;
+    return mgx_tconv_applicable(d) && d.kh >= 2 && d.sh == 1 && d.sw == 1 && d.ngemm == 32 && d.flip == 0;
 }
 
 bool mgx_pointwise2_applicable(const mgx_conv_desc& d);   // conv_gemm.hip

@@ -32,7 +32,11 @@ __global__ __launch_bounds__(512, 2) void tconv3_kernel(mgx_conv_desc d, const f
                                                         const float* __restrict__ w,
                                                         const float* __restrict__ bias, float* __restrict__ y,
                                                         float* __restrict__ dact, long ntiles, int tiles_h,
-                                                        int tiles_w) {
+                                                        int tiles_w, int gin_w, int scat) {
+    // gin_w > 0 (1x1 kernels only): the 128 input channels of position (i, j) are the 2x2 window at
+    // (2i, 2j) of a 32-channel image gin_w columns wide, slice kc = tap (kc / 2, kc % 2): a 2x2
+    // stride-2 convolution.  scat (1x1 kernels, 128 outputs): output channel block nc goes to
+    // position (2i + nc / 2, 2j + nc % 2) of a 32-channel image twice as large: its data-gradient.
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int IH = TH + KH - 1, IW = TW + KW - 1, TAPS = KH * KW, NPIX = IH * IW;
     constexpr int SITER = (NPIX * 8 + 511) / 512;      // float4 staging loads per thread (input tile)
@@ -88,13 +92,13 @@ __global__ __launch_bounds__(512, 2) void tconv3_kernel(mgx_conv_desc d, const f
         h0 = (int)th * TH;
         w0 = (int)(rem - th * tiles_w) * TW;
     };
-    const unsigned band_bytes = (unsigned)IH * W * d.cin * 4u;
+    const unsigned band_bytes = gin_w > 0 ? (unsigned)(2 * IH) * gin_w * 32u * 4u : (unsigned)IH * W * d.cin * 4u;
     int rel[SITER], tyx[SITER];          // byte offset of the element inside the tile window; (ty << 16) | tx
 #pragma unroll
     for (int i = 0; i < SITER; ++i) {
         const int px = (tid >> 3) + 64 * i;
         const int ty = px / IW, tx = px - ty * IW;
-        rel[i] = ((ty * W + tx) * d.cin + c4 * 4) * 4;
+        rel[i] = gin_w > 0 ? ((ty * 2 * gin_w + 2 * tx) * 32 + c4 * 4) * 4 : ((ty * W + tx) * d.cin + c4 * 4) * 4;
         tyx[i] = px < NPIX ? ((ty << 16) | tx) : (0x7000 << 16);      // never inside an image
     }
     f32x4 sv[SITER], sm[SITER];
@@ -102,8 +106,9 @@ __global__ __launch_bounds__(512, 2) void tconv3_kernel(mgx_conv_desc d, const f
         long img; int h0, w0;
         tile_of(t, img, h0, w0);
         const int hb = h0 - d.pt, wb = w0 - d.pl;
-        const int base = (wb * d.cin + kc * 32) * 4;
-        const long band = ((img * H + hb) * (long)W) * d.cin;      // first row of the window (may lie above the image)
+        const int base = gin_w > 0 ? ((2 * w0 + (kc & 1)) * 32 + (kc >> 1) * gin_w * 32) * 4 : (wb * d.cin + kc * 32) * 4;
+        // first row of the window (may lie above the image)
+        const long band = gin_w > 0 ? ((img * 2 * H + 2 * h0) * (long)gin_w) * 32 : ((img * H + hb) * (long)W) * d.cin;
         const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)(x + band), 0, band_bytes, 0x00020000);
         __amdgpu_buffer_rsrc_t rm = rx;
         if (MUL) rm = __builtin_amdgcn_make_buffer_rsrc((void*)(xmul + band), 0, band_bytes, 0x00020000);
@@ -147,16 +152,19 @@ __global__ __launch_bounds__(512, 2) void tconv3_kernel(mgx_conv_desc d, const f
     // past the row end are dropped by the hardware range check, the per-register part of the
     // offset is a scalar, so a store costs no vector ALU work.
     const int wvs = __builtin_amdgcn_readfirstlane(wv);
-    const unsigned row_bytes = (unsigned)W * d.ngemm * 4u;
     auto epilogue = [&](const f32x16& a, long t_, int oc_) {
         const int n = (nchunks > 1 ? oc_ : 0) * 32 + r;
         const float bv = d.nbias > 0 ? bias[n] : 0.f;
         long img; int h0, w0;
         tile_of(t_, img, h0, w0);
-        const long rowoff = ((img * H + h0 + wvs) * (long)W) * d.ngemm;
+        const int nc_ = nchunks > 1 ? oc_ : 0;
+        const long rowoff = scat ? ((img * 2 * H + 2 * (h0 + wvs) + (nc_ >> 1)) * (2L * W)) * 32
+                                 : ((img * H + h0 + wvs) * (long)W) * d.ngemm;
+        const unsigned row_bytes = scat ? 2u * W * 32u * 4u : (unsigned)W * d.ngemm * 4u;
         const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc((void*)(y + rowoff), 0, row_bytes, 0x00020000);
-        const unsigned voff = (unsigned)(((w0 + 4 * h) * d.ngemm + n) * 4);
-        const int rstep = d.ngemm * 4;                  // bytes per output position
+        const unsigned voff = scat ? (unsigned)(((2 * (w0 + 4 * h) + (nc_ & 1)) * 32 + r) * 4)
+                                   : (unsigned)(((w0 + 4 * h) * d.ngemm + n) * 4);
+        const int rstep = scat ? 2 * 32 * 4 : d.ngemm * 4;        // bytes per output position
         const bool act = d.act_alpha > 0.f;
         float v[16], der[16];
 #pragma unroll
@@ -265,7 +273,7 @@ __global__ __launch_bounds__(512, 2) void tconv3_kernel(mgx_conv_desc d, const f
 
 template <int KH, int KW>
 void launch3(const mgx_conv_desc& d, const float* x, const float* xmul, const float* w, const float* bias, float* y,
-             float* dact, hipStream_t st) {
+             float* dact, hipStream_t st, int gin_w = 0, int scat = 0) {
     const int tiles_h = d.hin / TH, tiles_w = (d.win + TW - 1) / TW;
     const long ntiles = (long)d.nimg * tiles_h * tiles_w;
     const unsigned grid = (unsigned)(ntiles < 256 ? ntiles : 256);
@@ -281,7 +289,7 @@ void launch3(const mgx_conv_desc& d, const float* x, const float* xmul, const fl
             allowed = true;                                                                                          \
         }                                                                                                            \
         hipLaunchKernelGGL((tconv3_kernel<KH, KW, WW, MM>), dim3(grid), dim3(512), lds, st, d, x, xmul, w, bias, y,   \
-                           dact, ntiles, tiles_h, tiles_w);                                                          \
+                           dact, ntiles, tiles_h, tiles_w, gin_w, scat);                                             \
     } while (0)
     if (wt) { if (mul) MGX_T3(true, true); else MGX_T3(true, false); }
     else { if (mul) MGX_T3(false, true); else MGX_T3(false, false); }
@@ -291,8 +299,19 @@ void launch3(const mgx_conv_desc& d, const float* x, const float* xmul, const fl
 }  // namespace
 
 // Runs the convolution described by d; applicability is checked by mgx_tconv_applicable (tconv.hip).
-int mgx_tconv3_launch(const mgx_conv_desc& d, const float* x, const float* xmul, const float* w, const float* bias,
+int mgx_tconv3_launch(const mgx_conv_desc& d0, const float* x, const float* xmul, const float* w, const float* bias,
                       float* y, float* dact, hipStream_t st) {
+    mgx_conv_desc d = d0;
+    if (d.sh == 2) {
+        // 2x2 stride-2 convolution = 1x1 convolution over the 128 channels of the gathered window
+        d.hin = d0.hout; d.win = d0.wout; d.cin = 128; d.kh = d.kw = 1; d.sh = d.sw = 1;
+        launch3<1, 1>(d, x, xmul, w, bias, y, dact, st, d0.win, 0);
+        return mgx_launch_status();
+    }
+    if (d.dkh == 2) {
+        launch3<1, 1>(d, x, xmul, w, bias, y, dact, st, 0, 1);
+        return mgx_launch_status();
+    }
     if (d.kh == 3) launch3<3, 3>(d, x, xmul, w, bias, y, dact, st);
     else if (d.kh == 2) launch3<2, 2>(d, x, xmul, w, bias, y, dact, st);
     else launch3<1, 1>(d, x, xmul, w, bias, y, dact, st);

@@ -85,7 +85,8 @@ def _gemm_key(d: ConvDesc, mul: bool = False) -> str:
     if route == 3:
         return "wino3_kernel"
     if route == 1:
-        return "tconv3_kernel<%d,%d,%s,%s>" % (d.kh, d.kw, "true" if d.wsk == 1 else "false",
+        kh, kw = (1, 1) if d.sh == 2 else (d.kh, d.kw)      # the strided form runs as a 1x1 kernel over gathered windows
+        return "tconv3_kernel<%d,%d,%s,%s>" % (kh, kw, "true" if d.wsk == 1 else "false",
                                                "true" if mul else "false")
     nt = (d.ngemm + 31) // 32
     pn = "4,1" if nt == 1 else ("2,2" if nt == 2 else "2,4")

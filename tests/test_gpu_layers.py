@@ -60,6 +60,8 @@ CONV_CASES = [
     (24, 95, 32, 32, (2, 2), (1, 1), "same", 1),
     (8, 50, 32, 32, (2, 2), (1, 1), "same", 2),       # 2x2 'same': pad 0 before / 1 after
     (8, 52, 32, 32, (2, 2), (2, 2), "valid", 3),
+    (16, 50, 32, 32, (2, 2), (2, 2), "valid", 3),     # tile kernel: stride-2 gather forward, depth-to-space data-gradient
+    (32, 132, 32, 32, (2, 2), (2, 2), "valid", 2),    # the same over two tile rows and three tile columns
     (6, 41, 2, 128, (1, 1), (1, 1), "same", 2),
     (6, 41, 32, 128, (1, 1), (1, 1), "same", 2),
     (1, 100, 2, 128, (1, 2), (1, 2), "valid", 5),     # generator stage-0 input conv
