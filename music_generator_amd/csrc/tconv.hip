@@ -195,10 +195,10 @@ bool mgx_tconv_applicable(const mgx_conv_desc& d) {
     if (d.cin % 32 || d.ngemm % 32 || d.cout != d.ngemm) return false;
     if (d.cin != 32 && d.ngemm != 32) return false;
     if (d.cin > 128 || d.ngemm > 128) return false;
-    if (d.hin % TH) return false;
+    if (d.hin % 4) return false;          // 8-row tiles, or 4-row tiles when the height is a multiple of 4 only
     // the tile kernels address one window of rows / one output row through 32-bit buffer offsets
     if ((long)(TH + 2) * d.win * (d.cin > d.ngemm ? d.cin : d.ngemm) * 4 >= (1L << 31)) return false;
-    if ((long)d.nimg * (d.hin / TH) * ((d.win + TW - 1) / TW) >= (1L << 31)) return false;
+    if ((long)d.nimg * (d.hin / 4) * ((d.win + TW - 1) / TW) >= (1L << 31)) return false;
     if (d.nbias != 0 && d.nbias != d.ngemm) return false;
     // dense weight slices per tap: [k][n] rows (forward) or [n][k] rows (data-gradient)
     const bool kn = d.wsn == 1 && d.wsk == d.ngemm;
@@ -218,7 +218,8 @@ int mgx_tconv_launch(const mgx_conv_desc& d, const float* x, const float* xmul, 
 
 // weight gradient: same applicability on the FORWARD descriptor, output channels must be 32
 bool mgx_twgrad_applicable(const mgx_conv_desc& d) {
-    return mgx_tconv_applicable(d) && d.kh >= 2 && d.sh == 1 && d.sw == 1 && d.ngemm == 32 && d.flip == 0;
+    return mgx_tconv_applicable(d) && d.hin % TH == 0 && d.kh >= 2 && d.sh == 1 && d.sw == 1 && d.ngemm == 32 &&
+           d.flip == 0;
 }
 
 bool mgx_pointwise2_applicable(const mgx_conv_desc& d);   // conv_gemm.hip

@@ -21,12 +21,15 @@
 
 namespace {
 
-constexpr int TH = 8, TW = 32, PSTR = 36;
+constexpr int PSTR = 36;
+// A tile is 256 output positions: TH = 8 rows x 32 columns (wave w owns row w) or, for images whose
+// height is a multiple of 4 only (the 4-row base block), TH = 4 rows x 64 columns (wave w owns row
+// w % 4, column half w / 4).
 
-template <int KH, int KW>
-constexpr int lds_floats() { return KH * KW * 1024 + 2 * (TH + KH - 1) * (TW + KW - 1) * PSTR; }
+template <int KH, int KW, int TH>
+constexpr int lds_floats() { return KH * KW * 1024 + 2 * (TH + KH - 1) * (256 / TH + KW - 1) * PSTR; }
 
-template <int KH, int KW, bool WT, bool MUL>
+template <int KH, int KW, bool WT, bool MUL, int TH>
 __global__ __launch_bounds__(512, 2) void tconv3_kernel(mgx_conv_desc d, const float* __restrict__ x,
                                                         const float* __restrict__ xmul,
                                                         const float* __restrict__ w,
@@ -38,6 +41,7 @@ __global__ __launch_bounds__(512, 2) void tconv3_kernel(mgx_conv_desc d, const f
     // stride-2 convolution.  scat (1x1 kernels, 128 outputs): output channel block nc goes to
     // position (2i + nc / 2, 2j + nc % 2) of a 32-channel image twice as large: its data-gradient.
     extern __shared__ __attribute__((aligned(16))) float lds[];
+    constexpr int TW = 256 / TH;
     constexpr int IH = TH + KH - 1, IW = TW + KW - 1, TAPS = KH * KW, NPIX = IH * IW;
     constexpr int SITER = (NPIX * 8 + 511) / 512;      // float4 staging loads per thread (input tile)
     constexpr int WITER = (TAPS * 256 + 511) / 512;    // float4 staging stores per thread (weights)
@@ -152,18 +156,19 @@ __global__ __launch_bounds__(512, 2) void tconv3_kernel(mgx_conv_desc d, const f
     // past the row end are dropped by the hardware range check, the per-register part of the
     // offset is a scalar, so a store costs no vector ALU work.
     const int wvs = __builtin_amdgcn_readfirstlane(wv);
+    const int wrow = TH == 8 ? wvs : (wvs & 3), wcol = TH == 8 ? 0 : (wvs >> 2) * 32;     // the wave's row and first column in the tile
     auto epilogue = [&](const f32x16& a, long t_, int oc_) {
         const int n = (nchunks > 1 ? oc_ : 0) * 32 + r;
         const float bv = d.nbias > 0 ? bias[n] : 0.f;
         long img; int h0, w0;
         tile_of(t_, img, h0, w0);
         const int nc_ = nchunks > 1 ? oc_ : 0;
-        const long rowoff = scat ? ((img * 2 * H + 2 * (h0 + wvs) + (nc_ >> 1)) * (2L * W)) * 32
-                                 : ((img * H + h0 + wvs) * (long)W) * d.ngemm;
+        const long rowoff = scat ? ((img * 2 * H + 2 * (h0 + wrow) + (nc_ >> 1)) * (2L * W)) * 32
+                                 : ((img * H + h0 + wrow) * (long)W) * d.ngemm;
         const unsigned row_bytes = scat ? 2u * W * 32u * 4u : (unsigned)W * d.ngemm * 4u;
         const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc((void*)(y + rowoff), 0, row_bytes, 0x00020000);
-        const unsigned voff = scat ? (unsigned)(((2 * (w0 + 4 * h) + (nc_ & 1)) * 32 + r) * 4)
-                                   : (unsigned)(((w0 + 4 * h) * d.ngemm + n) * 4);
+        const unsigned voff = scat ? (unsigned)(((2 * (w0 + wcol + 4 * h) + (nc_ & 1)) * 32 + r) * 4)
+                                   : (unsigned)(((w0 + wcol + 4 * h) * d.ngemm + n) * 4);
         const int rstep = scat ? 2 * 32 * 4 : d.ngemm * 4;        // bytes per output position
         const bool act = d.act_alpha > 0.f;
         float v[16], der[16];
@@ -227,7 +232,7 @@ __global__ __launch_bounds__(512, 2) void tconv3_kernel(mgx_conv_desc d, const f
         // before the MFMAs of quad q, so their latency is covered by 8 MFMAs of this wave
         {
             constexpr int NQ = 4 * TAPS;
-            const float* abase = xb + (wv * IW + r) * PSTR + 16 * h;
+            const float* abase = xb + (wrow * IW + wcol + r) * PSTR + 16 * h;
             const float* wbase = wl + (4 * h) * 128 + r * 4;
             f32x4 aq[3], wq[3];
             auto rd = [&](int q, int slot) {
@@ -271,24 +276,25 @@ __global__ __launch_bounds__(512, 2) void tconv3_kernel(mgx_conv_desc d, const f
     if (pend_valid) epilogue(pend, pend_t, pend_oc);
 }
 
-template <int KH, int KW>
+template <int KH, int KW, int TH = 8>
 void launch3(const mgx_conv_desc& d, const float* x, const float* xmul, const float* w, const float* bias, float* y,
              float* dact, hipStream_t st, int gin_w = 0, int scat = 0) {
+    constexpr int TW = 256 / TH;
     const int tiles_h = d.hin / TH, tiles_w = (d.win + TW - 1) / TW;
     const long ntiles = (long)d.nimg * tiles_h * tiles_w;
     const unsigned grid = (unsigned)(ntiles < 256 ? ntiles : 256);
-    constexpr int lds = lds_floats<KH, KW>() * 4;
+    constexpr int lds = lds_floats<KH, KW, TH>() * 4;
     const bool wt = d.wsk == 1, mul = xmul != nullptr;
     // more than 64 KiB of dynamic LDS must be allowed per kernel function
 #define MGX_T3(WW, MM)                                                                                               \
     do {                                                                                                             \
         static bool allowed = false;                                                                                 \
         if (!allowed) {                                                                                              \
-            (void)hipFuncSetAttribute((const void*)tconv3_kernel<KH, KW, WW, MM>,                                      \
+            (void)hipFuncSetAttribute((const void*)tconv3_kernel<KH, KW, WW, MM, TH>,                                      \
                                       hipFuncAttributeMaxDynamicSharedMemorySize, lds);                              \
             allowed = true;                                                                                          \
         }                                                                                                            \
-        hipLaunchKernelGGL((tconv3_kernel<KH, KW, WW, MM>), dim3(grid), dim3(512), lds, st, d, x, xmul, w, bias, y,   \
+        hipLaunchKernelGGL((tconv3_kernel<KH, KW, WW, MM, TH>), dim3(grid), dim3(512), lds, st, d, x, xmul, w, bias, y,   \
                            dact, ntiles, tiles_h, tiles_w, gin_w, scat);                                             \
     } while (0)
     if (wt) { if (mul) MGX_T3(true, true); else MGX_T3(true, false); }
@@ -310,6 +316,12 @@ int mgx_tconv3_launch(const mgx_conv_desc& d0, const float* x, const float* xmul
     }
     if (d.dkh == 2) {
         launch3<1, 1>(d, x, xmul, w, bias, y, dact, st, 0, 1);
+        return mgx_launch_status();
+    }
+    if (d.hin % 8) {                      // 4-row tiles: the 4 x 750 base block
+        if (d.kh == 3) launch3<3, 3, 4>(d, x, xmul, w, bias, y, dact, st);
+        else if (d.kh == 2) launch3<2, 2, 4>(d, x, xmul, w, bias, y, dact, st);
+        else launch3<1, 1, 4>(d, x, xmul, w, bias, y, dact, st);
         return mgx_launch_status();
     }
     if (d.kh == 3) launch3<3, 3>(d, x, xmul, w, bias, y, dact, st);
