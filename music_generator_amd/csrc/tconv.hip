@@ -35,13 +35,13 @@ struct Tile {
     int h0, w0;
 };
 
-__device__ __forceinline__ Tile decode_tile(long t, int tiles_h, int tiles_w) {
+__device__ __forceinline__ Tile decode_tile(long t, int tiles_h, int tiles_w, int rows = TH) {
     Tile q;
     const int per_img = tiles_h * tiles_w;
     q.img = t / per_img;
     const int rem = (int)(t - q.img * per_img);
     const int th = rem / tiles_w;
-    q.h0 = th * TH;
+    q.h0 = th * rows;
     q.w0 = (rem - th * tiles_w) * TW;
     return q;
 }
@@ -100,19 +100,20 @@ __device__ __forceinline__ void stage_tile(float* lds, const float* __restrict__
     }
 }
 
-template <int KH, int KW>
-constexpr int twgrad_lds_bytes() { return ((TH + KH - 1) * (TW + KW - 1) + TH * TW) * 32 * 4; }
+// RT = rows of a tile: 8, or 4 for images whose height is a multiple of 4 only (one row per wave)
+template <int KH, int KW, int RT = TH>
+constexpr int twgrad_lds_bytes() { return ((RT + KH - 1) * (TW + KW - 1) + RT * TW) * 32 * 4; }
 
-template <int KH, int KW>
+template <int KH, int KW, int RT>
 __global__ __launch_bounds__(256, 2) void twgrad_kernel(mgx_conv_desc d, const float* __restrict__ x,
                                                         const float* __restrict__ dy,
                                                         const float* __restrict__ dymul, float* __restrict__ partial,
                                                         float* __restrict__ bpartial, long ntiles, int tiles_h,
                                                         int tiles_w) {
     extern __shared__ __attribute__((aligned(16))) float lds[];
-    constexpr int IH = TH + KH - 1, IW = TW + KW - 1, TAPS = KH * KW;
+    constexpr int IH = RT + KH - 1, IW = TW + KW - 1, TAPS = KH * KW;
     float* xl = lds;                    // [IH*IW][32]
-    float* gl = lds + IH * IW * 32;     // [TH*TW][32]
+    float* gl = lds + IH * IW * 32;     // [RT*TW][32]
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int r = lane & 31, h = lane >> 5;
     const int H = d.hin, W = d.win;
@@ -127,16 +128,16 @@ __global__ __launch_bounds__(256, 2) void twgrad_kernel(mgx_conv_desc d, const f
     float bsum = 0.f;
 
     for (long t = blockIdx.x; t < ntiles; t += gridDim.x) {
-        const Tile q = decode_tile(t, tiles_h, tiles_w);
+        const Tile q = decode_tile(t, tiles_h, tiles_w, RT);
         __syncthreads();
         stage_tile<IH, IW, false>(xl, x, nullptr, q.img, q.h0 - d.pt, q.w0 - d.pl, H, W, d.cin, kc * 32);
-        if (dymul) stage_tile<TH, TW, true>(gl, dy, dymul, q.img, q.h0, q.w0, H, W, d.ngemm, 0);
-        else stage_tile<TH, TW, false>(gl, dy, dymul, q.img, q.h0, q.w0, H, W, d.ngemm, 0);
+        if (dymul) stage_tile<RT, TW, true>(gl, dy, dymul, q.img, q.h0, q.w0, H, W, d.ngemm, 0);
+        else stage_tile<RT, TW, false>(gl, dy, dymul, q.img, q.h0, q.w0, H, W, d.ngemm, 0);
         __syncthreads();
 #pragma unroll 4
-        for (int pp = 0; pp < 32; ++pp) {
-            const int px = pp * 2 + h;               // 0..63 within this wave's two rows
-            const int row = wv * 2 + (px >> 5), col = px & 31;
+        for (int pp = 0; pp < RT * 4; ++pp) {
+            const int px = pp * 2 + h;               // within this wave's RT/4 rows
+            const int row = wv * (RT / 4) + (px >> 5), col = px & 31;
             const float bv = gl[(row * TW + col) * 32 + r];
             bsum += bv;
 #pragma unroll
@@ -218,8 +219,7 @@ int mgx_tconv_launch(const mgx_conv_desc& d, const float* x, const float* xmul, 
 
 // weight gradient: same applicability on the FORWARD descriptor, output channels must be 32
 bool mgx_twgrad_applicable(const mgx_conv_desc& d) {
-    return mgx_tconv_applicable(d) && d.hin % TH == 0 && d.kh >= 2 && d.sh == 1 && d.sw == 1 && d.ngemm == 32 &&
-           d.flip == 0;
+    return mgx_tconv_applicable(d) && d.kh >= 2 && d.sh == 1 && d.sw == 1 && d.ngemm == 32 && d.flip == 0;
 }
 
 bool mgx_pointwise2_applicable(const mgx_conv_desc& d);   // conv_gemm.hip
@@ -241,21 +241,24 @@ extern "C" int mgx_conv_route(const mgx_conv_desc* d, int wgrad) {
 }
 
 long mgx_twgrad_splits(const mgx_conv_desc& d) {
-    const int tiles_h = d.hin / TH, tiles_w = (d.win + TW - 1) / TW;
+    const int rt = d.hin % TH ? 4 : TH;
+    const int tiles_h = d.hin / rt, tiles_w = (d.win + TW - 1) / TW;
     return (long)tile_grid((long)d.nimg * tiles_h * tiles_w) * 4;
 }
 
 int mgx_twgrad_launch(const mgx_conv_desc& d, const float* x, const float* dy, const float* dymul, float* partial,
                       float* bpartial, hipStream_t st) {
-    const int tiles_h = d.hin / TH, tiles_w = (d.win + TW - 1) / TW;
+    const int rt = d.hin % TH ? 4 : TH;
+    const int tiles_h = d.hin / rt, tiles_w = (d.win + TW - 1) / TW;
     const long ntiles = (long)d.nimg * tiles_h * tiles_w;
     dim3 grid(tile_grid(ntiles), d.cin / 32), block(256);
-    constexpr int lds3 = twgrad_lds_bytes<3, 3>(), lds2 = twgrad_lds_bytes<2, 2>();
-    if (d.kh == 3)
-        hipLaunchKernelGGL((twgrad_kernel<3, 3>), grid, block, lds3, st, d, x, dy, dymul, partial, bpartial, ntiles,
-                           tiles_h, tiles_w);
-    else
-        hipLaunchKernelGGL((twgrad_kernel<2, 2>), grid, block, lds2, st, d, x, dy, dymul, partial, bpartial, ntiles,
-                           tiles_h, tiles_w);
+#define MGX_TWGRAD(KK, RR)                                                                                         \
+    hipLaunchKernelGGL((twgrad_kernel<KK, KK, RR>), grid, block, (twgrad_lds_bytes<KK, KK, RR>()), st, d, x, dy,   \
+                       dymul, partial, bpartial, ntiles, tiles_h, tiles_w)
+    if (d.kh == 3 && rt == 8) MGX_TWGRAD(3, 8);
+    else if (d.kh == 3) MGX_TWGRAD(3, 4);
+    else if (rt == 8) MGX_TWGRAD(2, 8);
+    else MGX_TWGRAD(2, 4);
+#undef MGX_TWGRAD
     return mgx_launch_status();
 }
