@@ -671,9 +671,11 @@ class WGAN:
         self.last_losses = {"d_loss": out_d[0], "g_loss": out_g[0]}
         return {"delta_0": m0[3], "cu_0": m0[1], "ci_0": m0[2], "delta_1": m1[3], "cu_1": m1[1], "ci_1": m1[2]}
 
-    def fit(self, x, batch_size=32, epochs=1, callbacks=None, shuffle=True, verbose=0):
+    def fit(self, x, batch_size=32, epochs=1, callbacks=None, shuffle=True, verbose=0, initial_epoch=0):
         """keras.Model.fit for this custom step: per epoch a fresh permutation, full passes in
-        batches, History holds the last batch's metrics of every epoch."""
+        batches, History holds the last batch's metrics of every epoch.  `initial_epoch` (Keras'
+        argument of the same name) resumes a run: the permutations of the finished epochs are
+        drawn and dropped so that the remaining epochs see the batches they would have seen."""
         callbacks = list(callbacks or [])
         for cb in callbacks:
             cb.model = self
@@ -682,6 +684,8 @@ class WGAN:
         rng = np.random.default_rng(0)
         for epoch in range(epochs):
             order = rng.permutation(n) if shuffle else np.arange(n)
+            if epoch < initial_epoch:
+                continue
             logs = None
             for i in range(0, n, batch_size):
                 idx = order[i:i + batch_size]

@@ -34,15 +34,29 @@ def phase_steps(n_samples: int, n_batch: int, epochs: int) -> int:
 def train(g_models, d_models, gan_models, provider, batch_sizes: Sequence[int] = BATCH_SIZES,
           epochs_norm: Sequence[int] = EPOCHS_NORM, epochs_fade: Sequence[int] = EPOCHS_FADE,
           callbacks_for: Optional[Callable[[int, bool], list]] = None, shuffle_seed: int = 0,
-          verbose: int = 0) -> List[Dict[str, list]]:
-    """trainer/task.py:108-184.  Returns one History.history per fit call, in call order."""
+          verbose: int = 0, resume: Optional[Dict] = None) -> List[Dict[str, list]]:
+    """trainer/task.py:108-184.  Returns one History.history per fit call, in call order.
+
+    `resume` = the position checkpoint.load_checkpoint returns ({"stage", "fade_in", "epochs_done"}):
+    phases before it are skipped (their data shuffles are still drawn, so later phases see the
+    same order) and the phase it names continues after `epochs_done` epochs."""
     histories = []
     rng = np.random.default_rng(shuffle_seed)
 
+    def phase_rank(stage, fade):
+        return 2 * stage + (0 if fade or stage == 0 else 1)      # fade-in twin runs first within a stage
+
+    start = (phase_rank(int(resume["stage"]), bool(resume["fade_in"])), int(resume.get("epochs_done", 0))) \
+        if resume else (-1, 0)
+
     def run(gan, data, n_batch, epochs, stage, fade):
+        rank = phase_rank(stage, fade)
+        if rank < start[0]:
+            return
+        first = start[1] if rank == start[0] else 0
         gan.set_train_steps(phase_steps(data.shape[0], n_batch, epochs))
         cbs = callbacks_for(stage, fade) if callbacks_for else []
-        hist = gan.fit(data, batch_size=n_batch, epochs=epochs, callbacks=cbs, verbose=verbose)
+        hist = gan.fit(data, batch_size=n_batch, epochs=epochs, callbacks=cbs, verbose=verbose, initial_epoch=first)
         histories.append(hist.history)
 
     for i in range(len(g_models)):

@@ -259,3 +259,89 @@ def test_cabi_rejects_bad_arguments_before_touching_the_device():
         == _cabi.MGX_ERR_ARG
     assert lib.mgx_gblock_wgrad_f32(fake, fake, ctypes.byref(w), fake, 16, 3000, None) == _cabi.MGX_ERR_WORKSPACE
     assert lib.mgx_gblock_side_floats(1, 4, 750) == lib.mgx_gblock_side_floats_n(3000) == 24 * 4 * 4104 * 32
+
+
+def test_wav_sink_round_trip(tmp_path):
+    """(H, W, 2) clip -> (H*W, 2) float WAV at rate W (trainer/utils.py:84, 95, 108), read back
+    with scipy."""
+    from scipy.io import wavfile
+    from music_generator_amd import audio_out
+    rng = np.random.default_rng(3)
+    audio = rng.uniform(-0.5, 0.5, (3, 4, 750, 2)).astype(np.float32)
+    paths = audio_out.write_examples(audio, "gen", 7, out_dir=str(tmp_path))
+    assert [os.path.relpath(p, tmp_path) for p in paths] == ["4x750/gen0.wav", "4x750/gen7.wav", "4x750/gen14.wav"]
+    rate, sig = wavfile.read(paths[1])
+    assert rate == 750 and sig.dtype == np.float32 and sig.shape == (3000, 2)
+    assert np.array_equal(sig, audio[1].reshape(3000, 2))
+    sink = audio_out.WavSink(out_dir=str(tmp_path), prefix="s_", pick=2)
+    sink(5, 1, torch.from_numpy(audio))
+    rate, sig = wavfile.read(sink.written[0])
+    assert sink.written[0].endswith("4x750/s_epoch5_1.wav") and rate == 750
+    want = audio[2].reshape(3000, 2) / np.max(np.abs(audio[2].reshape(3000, 2)), axis=0)
+    assert np.allclose(sig, want, rtol=0, atol=1e-7) and np.max(np.abs(sig)) == pytest.approx(1.0)
+    silent = audio_out.clip_to_signal(np.zeros((4, 750, 2), np.float32), normalise=True)
+    assert np.all(silent == 0)
+    with pytest.raises(ValueError):
+        audio_out.clip_to_signal(np.zeros((4, 750, 3), np.float32))
+
+
+def test_checkpoint_restores_weights_counters_and_position(tmp_path):
+    """Host side of the checkpoint: every shared variable once, WGAN counters, schedule position;
+    a family of another depth is refused."""
+    from music_generator_amd import checkpoint
+    M.backend.clear_session()
+    d1, g1, c1 = task.build(2)
+    rng = np.random.default_rng(11)
+    variables = checkpoint._unique_variables([d1, g1])
+    assert len({id(v) for v in variables}) == len(variables)
+    for v in variables:
+        v.assign(rng.standard_normal(v.shape).astype(np.float32))
+    c1[1][1].actual_step, c1[1][1].total_steps, c1[1][1].train_steps = 17, 40, 60
+    c1[1][1].d_optimizer.iterations = 17
+    path = checkpoint.save_checkpoint(str(tmp_path / "ck"), d1, g1, c1, stage=1, fade_in=True, epochs_done=3,
+                                      extra={"note": "x"})
+    assert path.endswith("ck.npz") and not os.path.exists(path + ".tmp.npz")
+    d2, g2, c2 = task.build(2)              # fresh names (the session counters moved on), fresh values
+    pos = checkpoint.load_checkpoint(path, d2, g2, c2)
+    assert pos == {"stage": 1, "fade_in": True, "epochs_done": 3, "extra": {"note": "x"}}
+    for a, b in zip(variables, checkpoint._unique_variables([d2, g2])):
+        assert a.shape == b.shape and np.array_equal(a.numpy(), b.numpy())
+    assert (c2[1][1].actual_step, c2[1][1].total_steps, c2[1][1].train_steps) == (17, 40, 60)
+    assert c2[1][1].d_optimizer.iterations == 17 and c2[1][0].d_optimizer.iterations == 0
+    # sharing survives: the straight and fade-in twins still hold the same variable objects
+    last = lambda m: [l for l in m.layers if l.weights][-1].weights[0]
+    assert last(d2[1][0]) is last(d2[1][1])
+    d3, g3, c3 = task.build(3)
+    with pytest.raises(ValueError):
+        checkpoint.load_checkpoint(path, d3, g3, c3)
+
+
+def test_resume_skips_finished_phases():
+    """task.train(resume=...) runs only what is left: the named phase from `epochs_done` on, then
+    the later ones."""
+    calls = []
+
+    class FakeGan:
+        def __init__(self, tag):
+            self.tag = tag
+
+        def set_train_steps(self, n):
+            pass
+
+        def fit(self, data, batch_size, epochs, callbacks, verbose, initial_epoch):
+            calls.append((self.tag, epochs, initial_epoch))
+            return type("H", (), {"history": {}})()
+
+    class Shape:
+        def __init__(self, h, w):
+            self.output_shape = (None, h, w, 2)
+
+    g_models = [[Shape(4, 750)] * 2, [Shape(8, 1500)] * 2, [Shape(16, 3000)] * 2]
+    gans = [[FakeGan("s0"), FakeGan("s0f")], [FakeGan("s1"), FakeGan("s1f")], [FakeGan("s2"), FakeGan("s2f")]]
+    provider = lambda h, w: np.zeros((4, 1, 1, 2), np.float32)
+    task.train(g_models, None, gans, provider, batch_sizes=[2, 2, 2], epochs_norm=[5, 6, 7], epochs_fade=[0, 2, 3])
+    assert calls == [("s0", 5, 0), ("s1f", 2, 0), ("s1", 6, 0), ("s2f", 3, 0), ("s2", 7, 0)]
+    del calls[:]
+    task.train(g_models, None, gans, provider, batch_sizes=[2, 2, 2], epochs_norm=[5, 6, 7], epochs_fade=[0, 2, 3],
+               resume={"stage": 1, "fade_in": False, "epochs_done": 4})
+    assert calls == [("s1", 6, 4), ("s2f", 3, 0), ("s2", 7, 0)]
