@@ -95,8 +95,11 @@ def main():
         if world == 1 and args.gpus > 1:
             raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node %d bench.py --gpus %d ..."
                              % (args.gpus, args.gpus))
-    torch.cuda.set_device(local_rank)
-    dist = DataParallel(backend="nccl") if world > 1 else None
+    # one rank per GPU; MGX_BENCH_BACKEND=gloo rehearses the multi-rank flow on a box with fewer GPUs
+    # than ranks (RCCL refuses two ranks on one device)
+    backend = os.environ.get("MGX_BENCH_BACKEND", "nccl")
+    torch.cuda.set_device(local_rank % torch.cuda.device_count() if backend != "nccl" else local_rank)
+    dist = DataParallel(backend=backend) if world > 1 else None
 
     stage, fade = args.stage, (not args.straight and args.stage > 0)
     n_blocks = stage + 1
@@ -133,10 +136,12 @@ def main():
     elapsed = time.perf_counter() - t0
     ops.PROFILER = None
     if dist is not None:
-        t = torch.tensor([elapsed], device="cuda", dtype=torch.float64)
+        t = torch.tensor([elapsed], device="cuda" if backend == "nccl" else "cpu", dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         elapsed = float(t.item())
     last = {k: float(v) for k, v in metrics.items()}
+    if dist is not None:
+        torch.distributed.destroy_process_group()
     if not all(np.isfinite(list(last.values()))):
         raise SystemExit("non-finite metrics: %r" % (last,))
 
