@@ -198,6 +198,10 @@ int mgx_mbstd_bwd(const float* dy, const float* x, float* dx, int64_t n, int h, 
 int mgx_softrect_fwd(const float* x, float* y, int64_t n, float alpha, void* stream);
 int mgx_softrect_bwd(const float* dy, const float* x, float* dx, int accumulate, int64_t n, float alpha, void* stream);
 
+/* Row softmax: y[r, :] = softmax(x[r, :]), the activation of the evaluator's Dense(9) head
+ * (trainer/evaluacion.py:97), whose outputs feed calculate_inception_score (trainer/utils.py:65-76). */
+int mgx_softmax_rows(const float* x, float* y, int64_t rows, int cols, void* stream);
+
 /* Flatten + Dense(1) (models.py:339-340): y[i] = sum_e x[i,e]*w[e] + b.  Backward: dx[i,e] =
  * dy[i]*w[e] (if dx != NULL), dw[e] += sum_i dy[i]*x[i,e], db += sum_i dy[i] (if dw != NULL). */
 int mgx_dense1_fwd(const float* x, const float* w, const float* b, float* y, int64_t n, int64_t e, void* stream);

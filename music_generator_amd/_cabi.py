@@ -84,6 +84,7 @@ PROTOTYPES = {
     "mgx_mbstd_fwd": (_I, [_P, _P, _P, _I64, _I, _I, _I, _P, _I64, _P]),
     "mgx_mbstd_bwd": (_I, [_P, _P, _P, _I64, _I, _I, _I, _P, _I64, _P]),
     "mgx_softrect_fwd": (_I, [_P, _P, _I64, _F, _P]),
+    "mgx_softmax_rows": (_I, [_P, _P, _I64, _I, _P]),
     "mgx_softrect_bwd": (_I, [_P, _P, _P, _I, _I64, _F, _P]),
     "mgx_dense1_fwd": (_I, [_P, _P, _P, _P, _I64, _I64, _P]),
     "mgx_dense1_bwd": (_I, [_P, _P, _P, _P, _P, _P, _I64, _I64, _P]),

@@ -228,6 +228,24 @@ __global__ __launch_bounds__(1024) void adam_multi_kernel(float* const* __restri
     }
 }
 
+// Row softmax (the Dense(9, activation='softmax') head of the evaluator, evaluacion.py:97): one
+// wavefront per row, three passes over the row (max, sum of exp, write) with wave reductions.
+__global__ __launch_bounds__(64) void softmax_rows_kernel(const float* __restrict__ x, float* __restrict__ y, long rows,
+                                                          int cols) {
+    const int lane = threadIdx.x;
+    for (long r = blockIdx.x; r < rows; r += gridDim.x) {
+        const float* xr = x + r * cols;
+        float m = -INFINITY;
+        for (int c = lane; c < cols; c += 64) m = fmaxf(m, xr[c]);
+        for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+        float sum = 0.f;
+        for (int c = lane; c < cols; c += 64) sum += __expf(xr[c] - m);
+        for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+        const float inv = 1.f / sum;
+        for (int c = lane; c < cols; c += 64) y[r * cols + c] = __expf(xr[c] - m) * inv;
+    }
+}
+
 }  // namespace
 
 extern "C" int mgx_upsample2x_fwd(const float* x, float* y, int64_t nimg, int h, int w, int c, void* stream) {
@@ -303,6 +321,13 @@ extern "C" int mgx_weighted_sum_bwd(const float* dy, const float* a, const float
                        acc_b, part, (long)n);
     if (dalpha)
         hipLaunchKernelGGL(finish_sum_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, part, (int)grid, dalpha);
+    return mgx_launch_status();
+}
+
+extern "C" int mgx_softmax_rows(const float* x, float* y, int64_t rows, int cols, void* stream) {
+    if (!x || !y || rows <= 0 || cols <= 0) return MGX_ERR_ARG;
+    const unsigned grid = (unsigned)(rows < 65536 ? rows : 65536);
+    hipLaunchKernelGGL(softmax_rows_kernel, dim3(grid), dim3(64), 0, (hipStream_t)stream, x, y, (long)rows, cols);
     return mgx_launch_status();
 }
 

@@ -720,20 +720,35 @@ def define_composite(discriminators, generators, latent_dim, trainable_alpha=Tru
 class GANMonitor:
     """Epoch-end hook in the spirit of trainer/models.py:528-551: for straight-through models it
     draws `num_examples` batches of 10 clips from the generator (the inference call shape of
-    trainer/utils.py:103-104) and hands them to `sink(epoch, batch_index, audio)`.  The reference's
-    cloud upload, evaluator network and .h5 export are outside this package."""
+    trainer/utils.py:103-104), hands them to `sink(epoch, batch_index, audio)` when the epoch is a
+    `save_every`-th one (the reference's cadence is 10, models.py:541) and, when an evaluator model
+    is given, collects its class probabilities for all batches and records the epoch's Inception
+    score (utils.py:121-127) in `inception_scores[epoch + 1]`.  The reference's cloud upload and
+    .h5 export are outside this package."""
 
-    def __init__(self, job_dir=None, evaluador=None, num_examples=20, latent_dim=(1, 100, 2), sink=None):
+    def __init__(self, job_dir=None, evaluador=None, num_examples=20, latent_dim=(1, 100, 2), sink=None,
+                 save_every=1):
         self.num_examples = num_examples
         self.latent_dim = latent_dim
         self.job_dir = job_dir
         self.evaluador = evaluador
         self.sink = sink
+        self.save_every = int(save_every)
+        self.inception_scores: Dict[int, float] = {}
         self.model = None
 
     def on_epoch_end(self, epoch, logs=None):
-        if self.model is None or self.model.fade_in or self.sink is None:
+        if self.model is None or self.model.fade_in or (self.sink is None and self.evaluador is None):
             return
+        save = self.sink is not None and (epoch + 1) % self.save_every == 0
+        pred = []
         for i in range(self.num_examples):
             z = torch.randn((10,) + tuple(self.latent_dim), dtype=torch.float32, device=K.device())
-            self.sink(epoch, i, self.model.generator(z, training=False))
+            audio = self.model.generator(z, training=False)
+            if save:
+                self.sink(epoch, i, audio)
+            if self.evaluador is not None:
+                pred.append(self.evaluador(audio, training=False).cpu().numpy())
+        if pred:
+            from .evaluacion import calculate_inception_score
+            self.inception_scores[epoch + 1] = calculate_inception_score(np.concatenate(pred, axis=0))

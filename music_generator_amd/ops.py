@@ -382,6 +382,12 @@ def mbstd_bwd(dy, x, dx, n, h, w, c):
           "mgx_mbstd_bwd")
 
 
+def softmax_rows(x, y):
+    if x.dim() != 2 or x.shape != y.shape:
+        raise MgxError("softmax_rows: expected two (rows, cols) tensors of one shape")
+    check(_lib().mgx_softmax_rows(_p(x), _p(y), x.shape[0], x.shape[1], K.stream_ptr()), "mgx_softmax_rows")
+
+
 def softrect_fwd(x, y, alpha):
     if x.numel() != y.numel():
         raise MgxError("softrect_fwd: size mismatch")

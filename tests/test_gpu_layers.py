@@ -11,7 +11,7 @@ from music_generator_amd import layers as L
 from music_generator_amd.graph import Input, Model
 from oracle import ref_step as R
 
-from helpers import assert_close, randomize, run_single
+from helpers import assert_close, randomize, rel_l2, run_single
 
 pytestmark = pytest.mark.gpu
 
@@ -248,3 +248,52 @@ def test_adam_first_two_steps():
         assert_close(v.numpy(), p[v.name].numpy(), 1e-6, v.name)
     for k, val in opt.second_moments().items():
         assert_close(val, vs[k].numpy(), 1e-6, "v of " + k)
+
+
+@pytest.mark.parametrize("stage,batch", [(0, 3), (1, 2)])
+def test_evaluator_forward_matches_oracle(stage, batch):
+    """Evaluator inference (trainer/evaluacion.py:27-110; 128 -> 128 convolutions 1x1 / 3x3 / 4x4 /
+    2x2 'same' / 2x2 stride 2, Flatten, Dense(9), softmax) against the float64 restatement.  Weights
+    are scaled so that activations stay O(1) through the 10 / 19 linear layers; bounds: logits
+    rel-L2 1e-4, class probabilities abs 1e-5, Inception score rel 1e-5."""
+    import music_generator_amd as M
+    from music_generator_amd import evaluacion as E
+    from oracle import ref_evaluator as RE
+    M.clear_session()
+    model = E.define_evaluator(stage + 1)[stage]
+    rng = np.random.default_rng(40 + stage)
+    kernels, biases = [], []
+    convs = [l for l in model.layers if isinstance(l, M.layers.Conv2D)]
+    for l in convs:
+        fan_in = l.kernel_size[0] * l.kernel_size[1] * l.kernel.shape[2]
+        k = (rng.standard_normal(l.kernel.shape) / np.sqrt(fan_in)).astype(np.float32)
+        b = (0.05 * rng.standard_normal(l.bias.shape)).astype(np.float32)
+        l.kernel.assign(k), l.bias.assign(b)
+        kernels.append(k), biases.append(b)
+    head = model.layers[-1]
+    dk = (rng.standard_normal(head.kernel.shape) / np.sqrt(head.kernel.shape[0])).astype(np.float32)
+    db = (0.1 * rng.standard_normal(head.bias.shape)).astype(np.float32)
+    head.kernel.assign(dk), head.bias.assign(db)
+    x = rng.uniform(-1, 1, (batch, 4 << stage, 750 << stage, 2)).astype(np.float32)
+    probs = model(torch.from_numpy(x).cuda(), training=False).cpu().numpy()
+    logits_ref, probs_ref = RE.forward(stage, kernels, biases, dk, db, x)
+    assert probs.shape == (batch, 9) and np.allclose(probs.sum(axis=1), 1.0, atol=1e-6)
+    assert np.abs(probs - probs_ref).max() < 1e-5, np.abs(probs - probs_ref).max()
+    # logits recovered up to the row constant softmax removes
+    lg = np.log(probs.astype(np.float64))
+    lg += (logits_ref - lg).mean(axis=1, keepdims=True)
+    assert rel_l2(lg, logits_ref) < 1e-4, rel_l2(lg, logits_ref)
+    assert E.calculate_inception_score(probs) == pytest.approx(RE.inception_score(probs_ref), rel=1e-5)
+
+
+def test_softmax_rows_wide_and_saturated():
+    from music_generator_amd import ops
+    rng = np.random.default_rng(9)
+    x = rng.standard_normal((37, 200)).astype(np.float32) * 30.0       # wider than a wavefront, saturating
+    xd = torch.from_numpy(x).cuda()
+    y = torch.empty_like(xd)
+    ops.softmax_rows(xd, y)
+    want = torch.softmax(torch.from_numpy(x).double(), dim=1).numpy()
+    assert np.abs(y.cpu().numpy() - want).max() < 2e-6
+    with pytest.raises(ops.MgxError):
+        ops.softmax_rows(xd, torch.empty((37, 199), device="cuda"))

@@ -411,3 +411,25 @@ def test_checkpoint_resume_continues_bit_for_bit(tmp_path):
         assert np.array_equal(a, b.numpy()), b.name
     assert np.array_equal(final_v, comp2[1][0].g_optimizer._state["v"].cpu().numpy())
     assert comp2[1][1].actual_step == comp[1][1].actual_step and comp2[1][0].d_optimizer.iterations == 4
+
+
+def test_monitor_writes_audio_and_inception_score(tmp_path):
+    """The epoch-end hook of trainer/models.py:528-551 on the device: generator inference in
+    batches of 10, one peak-normalised WAV per batch on the saving epochs, evaluator predictions of
+    every batch folded into one Inception score per epoch (1 <= IS <= 9 classes)."""
+    from scipy.io import wavfile
+    from music_generator_amd import audio_out, evaluacion, task
+    M.clear_session()
+    d, g, comp = task.build(1)
+    comp[0][0].seed(3)
+    evaluador = evaluacion.define_evaluator(1)[0]
+    sink = audio_out.WavSink(out_dir=str(tmp_path), pick=None, seed=1)
+    monitor = M.GANMonitor(evaluador=evaluador, num_examples=2, sink=sink, save_every=2)
+    task.train(g, d, comp, task.synthetic_provider(4, seed=2), batch_sizes=[4], epochs_norm=[2], epochs_fade=[0],
+               callbacks_for=lambda stage, fade: [monitor])
+    assert sorted(monitor.inception_scores) == [1, 2]
+    assert all(1.0 - 1e-6 <= v <= 9.0 + 1e-6 for v in monitor.inception_scores.values())
+    assert [os.path.relpath(p, tmp_path) for p in sink.written] == ["4x750/epoch1_0.wav", "4x750/epoch1_1.wav"]
+    rate, sig = wavfile.read(sink.written[0])
+    assert rate == 750 and sig.shape == (3000, 2) and np.isfinite(sig).all()
+    assert np.abs(sig).max(axis=0) == pytest.approx([1.0, 1.0])

@@ -345,3 +345,27 @@ def test_resume_skips_finished_phases():
     task.train(g_models, None, gans, provider, batch_sizes=[2, 2, 2], epochs_norm=[5, 6, 7], epochs_fade=[0, 2, 3],
                resume={"stage": 1, "fade_in": False, "epochs_done": 4})
     assert calls == [("s1", 6, 4), ("s2f", 3, 0), ("s2", 7, 0)]
+
+
+def test_evaluator_family_structure_and_inception_score():
+    """trainer/evaluacion.py:27-110: per stage the convolution list the oracle replays, old layers
+    shared from index 3 on, (None, 9) outputs; trainer/utils.py:65-76 against explicit loops."""
+    from music_generator_amd import evaluacion as E
+    from oracle import ref_evaluator as RE
+    M.backend.clear_session()
+    ev = E.define_evaluator(3)
+    for s, m in enumerate(ev):
+        convs = [l for l in m.layers if isinstance(l, Conv2D)]
+        assert [(l.kernel_size[0], l.kernel_size[1], l.strides[0], l.padding) for l in convs] == RE.conv_specs(s)
+        assert all(l.filters == 128 for l in convs)
+        assert m.input.shape == (None, 4 << s, 750 << s, 2) and m.output_shape == (None, 9)
+        assert isinstance(m.layers[-1], Dense) and m.layers[-1].units == 9
+    assert ev[1].layers[-1] is ev[0].layers[-1] and ev[2].layers[-3] is ev[0].layers[-3]
+    assert ev[0].layers[2] not in ev[1].layers              # the old first 3x3 convolution is dropped
+    assert ev[0].layers[3] in ev[1].layers
+    rng = np.random.default_rng(0)
+    p = rng.uniform(0.01, 1.0, (7, 9))
+    p /= p.sum(axis=1, keepdims=True)
+    assert E.calculate_inception_score(p) == pytest.approx(RE.inception_score(p), rel=1e-12)
+    assert E.calculate_inception_score(np.full((5, 9), 1 / 9.0)) == pytest.approx(1.0)
+    assert E.calculate_inception_score(np.eye(9)) == pytest.approx(9.0, rel=1e-9)
