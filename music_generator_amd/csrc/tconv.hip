@@ -10,6 +10,7 @@
 // the whole launch; the grid is persistent and every wave writes one slab of partial sums that
 // conv_wgrad.hip adds in fixed order.  Input chunks of 128-channel convolutions are blockIdx.y.
 #include "common.h"
+#include "wino.h"
 #include "../../include/mgx.h"
 
 #include <type_traits>
@@ -104,8 +105,10 @@ __device__ __forceinline__ void stage_tile(float* lds, const float* __restrict__
 template <int KH, int KW, int RT = TH>
 constexpr int twgrad_lds_bytes() { return ((RT + KH - 1) * (TW + KW - 1) + RT * TW) * 32 * 4; }
 
+// A 4x4 kernel keeps 16 accumulator tiles = all 256 accumulation registers of a wave: one wave per
+// SIMD, MFMAs through the asm form that pins the accumulators there.
 template <int KH, int KW, int RT>
-__global__ __launch_bounds__(256, 2) void twgrad_kernel(mgx_conv_desc d, const float* __restrict__ x,
+__global__ __launch_bounds__(256, KH * KW == 16 ? 1 : 2) void twgrad_kernel(mgx_conv_desc d, const float* __restrict__ x,
                                                         const float* __restrict__ dy,
                                                         const float* __restrict__ dymul, float* __restrict__ partial,
                                                         float* __restrict__ bpartial, long ntiles, int tiles_h,
@@ -145,7 +148,8 @@ __global__ __launch_bounds__(256, 2) void twgrad_kernel(mgx_conv_desc d, const f
 #pragma unroll
                 for (int b = 0; b < KW; ++b) {
                     const float av = xl[((row + a) * IW + (col + b)) * 32 + r];
-                    acc[a * KW + b] = mfma32(av, bv, acc[a * KW + b]);
+                    if constexpr (TAPS == 16) mfma_acc(acc[a * KW + b], av, bv);
+                    else acc[a * KW + b] = mfma32(av, bv, acc[a * KW + b]);
                 }
         }
     }
@@ -189,7 +193,8 @@ static bool strided2_applicable(const mgx_conv_desc& d) {
 
 bool mgx_tconv_applicable(const mgx_conv_desc& d) {
     if (strided2_applicable(d)) return true;
-    if (d.kh != d.kw || d.kh < 1 || d.kh > 3) return false;
+    if (d.kh != d.kw || d.kh < 1 || d.kh > 4) return false;
+    if (d.kh == 4 && (d.cin != 32 || d.ngemm != 32)) return false;   // 16 weight slices: one 32x32 slice per tap
     if (d.sh != 1 || d.sw != 1 || d.dkh != 1 || d.dkw != 1) return false;
     if (d.hout != d.hin || d.wout != d.win) return false;
     if (d.pt < 0 || d.pt >= d.kh || d.pl < 0 || d.pl >= d.kw) return false;
@@ -198,7 +203,7 @@ bool mgx_tconv_applicable(const mgx_conv_desc& d) {
     if (d.cin > 128 || d.ngemm > 128) return false;
     if (d.hin % 4) return false;          // 8-row tiles, or 4-row tiles when the height is a multiple of 4 only
     // the tile kernels address one window of rows / one output row through 32-bit buffer offsets
-    if ((long)(TH + 2) * d.win * (d.cin > d.ngemm ? d.cin : d.ngemm) * 4 >= (1L << 31)) return false;
+    if ((long)(TH + 3) * d.win * (d.cin > d.ngemm ? d.cin : d.ngemm) * 4 >= (1L << 31)) return false;
     if ((long)d.nimg * (d.hin / 4) * ((d.win + TW - 1) / TW) >= (1L << 31)) return false;
     if (d.nbias != 0 && d.nbias != d.ngemm) return false;
     // dense weight slices per tap: [k][n] rows (forward) or [n][k] rows (data-gradient)
@@ -241,21 +246,22 @@ extern "C" int mgx_conv_route(const mgx_conv_desc* d, int wgrad) {
 }
 
 long mgx_twgrad_splits(const mgx_conv_desc& d) {
-    const int rt = d.hin % TH ? 4 : TH;
+    const int rt = (d.hin % TH || d.kh == 4) ? 4 : TH;
     const int tiles_h = d.hin / rt, tiles_w = (d.win + TW - 1) / TW;
     return (long)tile_grid((long)d.nimg * tiles_h * tiles_w) * 4;
 }
 
 int mgx_twgrad_launch(const mgx_conv_desc& d, const float* x, const float* dy, const float* dymul, float* partial,
                       float* bpartial, hipStream_t st) {
-    const int rt = d.hin % TH ? 4 : TH;
+    const int rt = (d.hin % TH || d.kh == 4) ? 4 : TH;
     const int tiles_h = d.hin / rt, tiles_w = (d.win + TW - 1) / TW;
     const long ntiles = (long)d.nimg * tiles_h * tiles_w;
     dim3 grid(tile_grid(ntiles), d.cin / 32), block(256);
 #define MGX_TWGRAD(KK, RR)                                                                                         \
     hipLaunchKernelGGL((twgrad_kernel<KK, KK, RR>), grid, block, (twgrad_lds_bytes<KK, KK, RR>()), st, d, x, dy,   \
                        dymul, partial, bpartial, ntiles, tiles_h, tiles_w)
-    if (d.kh == 3 && rt == 8) MGX_TWGRAD(3, 8);
+    if (d.kh == 4) MGX_TWGRAD(4, 4);
+    else if (d.kh == 3 && rt == 8) MGX_TWGRAD(3, 8);
     else if (d.kh == 3) MGX_TWGRAD(3, 4);
     else if (rt == 8) MGX_TWGRAD(2, 8);
     else MGX_TWGRAD(2, 4);

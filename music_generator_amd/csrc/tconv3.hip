@@ -1,4 +1,4 @@
-// Stride-1 'same' convolution (3x3 / 2x2 / 1x1) of one 32-channel input slice into one 32-channel
+// Stride-1 'same' convolution (4x4 / 3x3 / 2x2 / 1x1) of one 32-channel input slice into one 32-channel
 // output slice on v_mfma_f32_32x32x2_f32 — forward and data-gradient of the discriminator convs.
 //
 // One workgroup of 8 waves per CU walks tiles of 8 rows x 32 columns; wave w owns row w (one
@@ -26,8 +26,15 @@ constexpr int PSTR = 36;
 // height is a multiple of 4 only (the 4-row base block), TH = 4 rows x 64 columns (wave w owns row
 // w % 4, column half w / 4).
 
+// The 16 weight slices of a 4x4 kernel leave room for one input tile only: its next tile waits in
+// registers until every wave is done with the current one (one more barrier per tile).
+template <int KH>
+constexpr int input_buffers() { return KH == 4 ? 1 : 2; }
+
 template <int KH, int KW, int TH>
-constexpr int lds_floats() { return KH * KW * 1024 + 2 * (TH + KH - 1) * (256 / TH + KW - 1) * PSTR; }
+constexpr int lds_floats() {
+    return KH * KW * 1024 + input_buffers<KH>() * (TH + KH - 1) * (256 / TH + KW - 1) * PSTR;
+}
 
 template <int KH, int KW, bool WT, bool MUL, int TH>
 __global__ __launch_bounds__(512, 2) void tconv3_kernel(mgx_conv_desc d, const float* __restrict__ x,
@@ -43,10 +50,11 @@ __global__ __launch_bounds__(512, 2) void tconv3_kernel(mgx_conv_desc d, const f
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int TW = 256 / TH;
     constexpr int IH = TH + KH - 1, IW = TW + KW - 1, TAPS = KH * KW, NPIX = IH * IW;
+    constexpr int NBUF = input_buffers<KH>();
     constexpr int SITER = (NPIX * 8 + 511) / 512;      // float4 staging loads per thread (input tile)
     constexpr int WITER = (TAPS * 256 + 511) / 512;    // float4 staging stores per thread (weights)
     float* wl = lds;                                   // [TAPS][8][32][4]
-    float* xt = lds + TAPS * 1024;                     // [2][NPIX][36]
+    float* xt = lds + TAPS * 1024;                     // [NBUF][NPIX][36]
     const int tid = threadIdx.x;
     const int lane = tid & 63, wv = tid >> 6;
     const int r = lane & 31, h = lane >> 5;
@@ -251,8 +259,8 @@ __global__ __launch_bounds__(512, 2) void tconv3_kernel(mgx_conv_desc d, const f
                 __builtin_amdgcn_sched_barrier(0);
             }
         }
-        if (S > 1) __syncthreads();        // every wave is done with the weight slice
-        if (need_x) stage_write(xt + (cur ^ 1) * (NPIX * PSTR));
+        if (S > 1 || NBUF == 1) __syncthreads();        // every wave is done with the weight slice (the input tile)
+        if (need_x) stage_write(xt + (NBUF == 1 ? 0 : (cur ^ 1)) * (NPIX * PSTR));
         if (need_w) w_write();
         // the stores of the epilogue come after the staging writes: the wait for the staged loads
         // must not also wait for stores that were issued a moment ago
@@ -269,7 +277,7 @@ __global__ __launch_bounds__(512, 2) void tconv3_kernel(mgx_conv_desc d, const f
             for (int reg = 0; reg < 16; ++reg) acc[reg] = 0.f;
         }
         __syncthreads();
-        if (need_x) cur ^= 1;
+        if (need_x && NBUF == 2) cur ^= 1;
         t = tn;
         oc = ocn;
     }
@@ -316,6 +324,10 @@ int mgx_tconv3_launch(const mgx_conv_desc& d0, const float* x, const float* xmul
     }
     if (d.dkh == 2) {
         launch3<1, 1>(d, x, xmul, w, bias, y, dact, st, 0, 1);
+        return mgx_launch_status();
+    }
+    if (d.kh == 4) {                      // 32 -> 32 only (mgx_tconv_applicable), always on 4-row tiles
+        launch3<4, 4, 4>(d, x, xmul, w, bias, y, dact, st);
         return mgx_launch_status();
     }
     if (d.hin % 8) {                      // 4-row tiles: the 4 x 750 base block

@@ -50,6 +50,8 @@ CONV_CASES = [
     # (H, W, Cin, Cout, ksize, strides, padding, batch)
     (4, 37, 128, 32, (3, 3), (1, 1), "same", 3),
     (4, 75, 32, 32, (4, 4), (1, 1), "same", 2),       # 4x4 'same' on H=4: pad 1 before / 2 after
+    (4, 750, 32, 32, (4, 4), (1, 1), "same", 3),      # 4x4 tile kernel: 12 column tiles of 64, ragged last one
+    (8, 130, 32, 32, (4, 4), (1, 1), "same", 2),      # 4x4 tile kernel over two tile rows of 4
     (8, 50, 32, 32, (3, 3), (1, 1), "same", 2),
     (16, 70, 128, 32, (3, 3), (1, 1), "same", 2),     # LDS-tiled path, 4 input-channel chunks
     (8, 33, 32, 32, (3, 3), (1, 1), "same", 3),       # LDS-tiled path, ragged right edge

@@ -240,8 +240,12 @@ def test_cabi_rejects_bad_arguments_before_touching_the_device():
     wino = 3 if os.environ.get("MGX_WINOGRAD", "1") != "0" else 1
     assert lib.mgx_conv_route(ctypes.byref(d), 0) == wino and lib.mgx_conv_route(ctypes.byref(d), 1) == wino
     assert lib.mgx_conv_route(ctypes.byref(d), 2) == wino          # with an input multiplier: 32 channels, linear
-    d.hin = d.hout = 4                                   # 4-row tiles of the direct kernel; the weight gradient is generic
+    d.hin = d.hout = 4                                   # 4-row tiles of the direct kernels
     assert lib.mgx_conv_route(ctypes.byref(d), 0) == 1 and lib.mgx_conv_route(ctypes.byref(d), 1) == 1
+    d.kh = d.kw = 4                                      # 4x4 'same' 32 -> 32: tile kernels too (weights 16 x 1024)
+    d.wtap = 1024
+    assert lib.mgx_conv_route(ctypes.byref(d), 0) == 1 and lib.mgx_conv_route(ctypes.byref(d), 1) == 1
+    d.kh = d.kw = 3
     d.hin = d.hout = 6                                   # not a multiple of 4: generic kernel
     assert lib.mgx_conv_route(ctypes.byref(d), 0) == 0
     # fused generator block: unset weight pointers, misaligned range, short workspace
