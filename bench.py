@@ -80,6 +80,9 @@ def main():
     ap.add_argument("--reuse-real-logits", action="store_true",
                     help="evaluate discriminator(real) once after the D update instead of three times (same values)")
     ap.add_argument("--cpu-sample-batch", type=int, default=2)
+    ap.add_argument("--graph", action="store_true",
+                    help="replay the step as one HIP graph (WGAN.use_graph): for small batches, where the host's "
+                         "launch rate bounds the step; no per-kernel roofline in this mode")
     ap.add_argument("--host-input", action="store_true",
                     help="hand every step a host (numpy) batch, so the host-to-device copy is inside the timed "
                          "region: the PCIe-inclusive rate, not the headline value")
@@ -113,6 +116,11 @@ def main():
     gan = comp[stage][1 if fade else 0]
     gan.dist = dist
     gan.reuse_real_logits = args.reuse_real_logits
+    if args.graph:
+        if world > 1:
+            raise SystemExit("--graph is a single-GPU mode")
+        gan.use_graph = True
+        args.warmup = max(args.warmup, 2)        # eager step, then the capturing step
     if dist is not None:
         dist.broadcast_weights(gan.discriminator, gan.generator)
     gan.set_train_steps(100)
@@ -133,7 +141,7 @@ def main():
     for _ in range(args.warmup):
         gan.train_step(real)
     sync()
-    prof = ops.LaunchProfiler()
+    prof = None if args.graph else ops.LaunchProfiler()
     ops.PROFILER = prof
     t0 = time.perf_counter()
     for _ in range(args.steps):
@@ -156,6 +164,16 @@ def main():
     ms_per_step = elapsed / args.steps * 1e3
     global_batch = args.batch * world
     value = global_batch * args.steps / elapsed
+    if prof is None:
+        print(json.dumps({"metric": "G+D train-step samples/sec", "value": round(value, 3), "unit": "samples/s",
+                          "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
+                          "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak",
+                          "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+                          "config": {"workload": "stage-%d (%dx%d) %s G+D train step, batch %d, fp32, HIP graph replay"
+                                                 % (stage, h, w, "fade-in" if fade else "straight-through", args.batch)},
+                          "step_tflops_algorithmic": round(STEP_GFLOP_PER_SAMPLE[stage] * args.batch / ms_per_step, 2),
+                          "last_metrics": last}))
+        return
     summ = prof.summary()
     # bandwidth-bound kernels (zero FLOPs recorded): achieved GB/s against the 8 TB/s HBM peak
     hbm_ops = {k: {"launches": v[0], "ms": round(v[1], 3), "GB/s": round(v[3] / v[1] / 1e6, 1),

@@ -235,6 +235,12 @@ int mgx_combine_grads(float* out, const float* a, const float* b, const float* c
 int mgx_adam_multi(float* const* p, const int64_t* n, const int64_t* off, const float* g, float* v,
                    const int32_t* blk_tensor, const int64_t* blk_start, int64_t nblocks,
                    float lr_t, float beta2, float eps, void* stream);
+/* The same update with the step size lr_t = lr*sqrt(1-beta2^t) (keras OptimizerV2, the optimisers of
+ * models.py:502-503) read from device memory at execution time: a train step captured once into a HIP
+ * graph is replayed with a new t by rewriting that one float before the replay. */
+int mgx_adam_multi_devlr(float* const* p, const int64_t* n, const int64_t* off, const float* g, float* v,
+                         const int32_t* blk_tensor, const int64_t* blk_start, int64_t nblocks,
+                         const float* lr_t, float beta2, float eps, void* stream);
 
 #ifdef __cplusplus
 }

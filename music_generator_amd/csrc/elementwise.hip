@@ -207,8 +207,9 @@ __global__ __launch_bounds__(kBlock) void softrect_bwd_kernel(const float* __res
 __global__ __launch_bounds__(1024) void adam_multi_kernel(float* const* __restrict__ p, const int64_t* __restrict__ n,
                                                           const int64_t* __restrict__ off, const float* __restrict__ g,
                                                           float* __restrict__ v, const int32_t* __restrict__ blk_tensor,
-                                                          const int64_t* __restrict__ blk_start, float lr_t, float beta2,
-                                                          float eps) {
+                                                          const int64_t* __restrict__ blk_start, float lr_host,
+                                                          const float* __restrict__ lr_dev, float beta2, float eps) {
+    const float lr_t = lr_dev ? lr_dev[0] : lr_host;
     const int t = blk_tensor[blockIdx.x];
     const int64_t start = blk_start[blockIdx.x];
     const int64_t cnt = n[t];
@@ -352,6 +353,16 @@ extern "C" int mgx_adam_multi(float* const* p, const int64_t* n, const int64_t* 
     if (!p || !n || !off || !g || !v || !blk_tensor || !blk_start || nblocks <= 0 || nblocks > 0x7fffffffL)
         return MGX_ERR_ARG;
     hipLaunchKernelGGL(adam_multi_kernel, dim3((unsigned)nblocks), dim3(1024), 0, (hipStream_t)stream, p, n, off, g, v,
-                       blk_tensor, blk_start, lr_t, beta2, eps);
+                       blk_tensor, blk_start, lr_t, (const float*)nullptr, beta2, eps);
+    return mgx_launch_status();
+}
+
+extern "C" int mgx_adam_multi_devlr(float* const* p, const int64_t* n, const int64_t* off, const float* g, float* v,
+                                    const int32_t* blk_tensor, const int64_t* blk_start, int64_t nblocks,
+                                    const float* lr_t, float beta2, float eps, void* stream) {
+    if (!p || !n || !off || !g || !v || !blk_tensor || !blk_start || !lr_t || nblocks <= 0 || nblocks > 0x7fffffffL)
+        return MGX_ERR_ARG;
+    hipLaunchKernelGGL(adam_multi_kernel, dim3((unsigned)nblocks), dim3(1024), 0, (hipStream_t)stream, p, n, off, g, v,
+                       blk_tensor, blk_start, 0.f, lr_t, beta2, eps);
     return mgx_launch_status();
 }

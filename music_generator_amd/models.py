@@ -420,16 +420,22 @@ class Adam:
             blk_t=torch.tensor(blk_t, dtype=torch.int32, device=dev),
             blk_s=torch.tensor(blk_s, dtype=torch.int64, device=dev), nblocks=len(blk_t))
 
-    def apply_model_gradients(self, model: Model):
+    def next_step_size(self) -> float:
+        """Count one more update and return its lr_t = lr * sqrt(1 - beta_2^t)."""
+        self.iterations += 1
+        return self.lr * math.sqrt(1.0 - self.beta_2 ** self.iterations)
+
+    def apply_model_gradients(self, model: Model, lr_dev: Optional[torch.Tensor] = None):
         """Adam.apply_gradients(zip(grads, model.trainable_variables)) for gradients held in the
-        model's flat gradient buffer."""
+        model's flat gradient buffer.  `lr_dev` (a 1-element device tensor holding lr_t): the update
+        reads its step size from there and the iteration count is the caller's business (a step
+        captured into a HIP graph; WGAN writes next_step_size() into the tensor before each replay)."""
         if self._state is None:
             self._build(model)
         st = self._state
         if st["model"] is not model:
             raise RuntimeError("an Adam instance is bound to the first model it updates")
-        self.iterations += 1
-        lr_t = self.lr * math.sqrt(1.0 - self.beta_2 ** self.iterations)
+        lr_t = lr_dev if lr_dev is not None else self.next_step_size()
         ops.adam_multi(st["p"], st["n"], st["off"], model.bind_grads(), st["v"], st["blk_t"], st["blk_s"],
                        st["nblocks"], lr_t, self.beta_2, self.epsilon)
 
@@ -469,6 +475,11 @@ class WGAN:
         # re-uses the logit sum: same values bit for bit, two discriminator forwards less per step.
         # Off by default so that a step runs every pass the reference runs.
         self.reuse_real_logits = False
+        # True: train_step captures the whole step into one HIP graph (per batch shape) the second
+        # time it sees a shape and replays it from then on; see _graphed_step.
+        self.use_graph = False
+        self._graphs: Dict = {}
+        self._scalars = None                  # device [alpha, lr_t of D, lr_t of G] while capturing
         self._mb_cache: Dict = {}
         self._ones_cache: Dict = {}
         self._latents: List = []
@@ -570,18 +581,92 @@ class WGAN:
         soon as it has been forwarded; the fake-pass and real-pass gradient sums are scaled by the
         two constants once the batch-wide sign is known.  A step therefore costs the same number
         of passes with or without micro-batching, and needs one micro-batch of activations."""
-        if self.fade_in:
-            if self.train_steps is None or self.train_steps < 2:
-                raise ValueError("fade-in needs set_train_steps(n) with n >= 2 (alpha = step/(n-1))")
-            alpha = self.actual_step / float(self.train_steps - 1)
-            for model in (self.discriminator, self.generator):
-                for layer in model.layers:
-                    if isinstance(layer, WeightedSum):
-                        backend.set_value(layer.alpha, alpha)
         if isinstance(real_images, tuple):
             real_images = real_images[0]
+        alpha = self._fade_alpha()              # validates set_train_steps before anything touches the device
+        real = self.discriminator._to_device(real_images)
+        if self.use_graph:
+            return self._graphed_step(real)
+        if alpha is not None:
+            for layer in self._fade_layers():
+                backend.set_value(layer.alpha, alpha)
+        out = self._step_body(real)
+        self.actual_step += 1
+        return out
+
+    def _fade_alpha(self):
+        """models.py:78-82: alpha = actual_step / (train_steps - 1) on fade-in models."""
+        if not self.fade_in:
+            return None
+        if self.train_steps is None or self.train_steps < 2:
+            raise ValueError("fade-in needs set_train_steps(n) with n >= 2 (alpha = step/(n-1))")
+        return self.actual_step / float(self.train_steps - 1)
+
+    def _fade_layers(self):
+        return [layer for model in (self.discriminator, self.generator) for layer in model.layers
+                if isinstance(layer, WeightedSum)]
+
+    def _graphed_step(self, real):
+        """The step as one HIP graph.  A small step is bound by the cost of enqueueing its ~10^3
+        kernels from the host, not by the GPU; captured once, the whole step is a single launch.
+        What changes from step to step lives in device memory the graph reads: the batch (copied
+        into a fixed buffer), three scalars (fade-in alpha and the two Adam step sizes, written
+        before every replay) and the state of the latent generator (advanced by the graph).  The
+        first step of a batch shape runs eagerly (it sizes every cache and workspace), the second
+        one is captured.  The returned metric tensors are the graph's own: the next step overwrites
+        them."""
+        if self.dist is not None:
+            raise NotImplementedError("graph replay covers the single-GPU step; collectives are not captured")
+        if self.d_steps != 1:
+            raise NotImplementedError("graph replay is written for one discriminator update per step "
+                                      "(define_composite's setting)")
+        if self._latents:
+            raise RuntimeError("injected latents cannot be used with use_graph (the graph draws its own)")
+        if ops.PROFILER is not None:
+            raise RuntimeError("per-launch profiling and graph capture exclude each other")
+        key = tuple(real.shape)
+        entry = self._graphs.get(key)
+        alpha = self._fade_alpha()
+        if entry is None:                       # first sight of this shape: ordinary step, caches warm up
+            self._graphs[key] = {"graph": None}
+            if alpha is not None:
+                for layer in self._fade_layers():
+                    backend.set_value(layer.alpha, alpha)
+            out = self._step_body(real)
+            self.actual_step += 1
+            return out
+        if entry["graph"] is None:
+            entry["real"] = torch.empty_like(real)
+            entry["scal"] = torch.zeros((3,), dtype=torch.float32, device=real.device)
+            entry["host"] = torch.zeros((3,), dtype=torch.float32).pin_memory()
+            graph = torch.cuda.CUDAGraph()
+            if self._rng is not None:
+                graph.register_generator_state(self._rng)
+            torch.cuda.synchronize()
+            self._scalars = entry["scal"]
+            try:
+                with torch.cuda.graph(graph):
+                    if alpha is not None:
+                        for layer in self._fade_layers():
+                            layer.alpha.value().copy_(entry["scal"][0:1])
+                    entry["out"] = self._step_body(entry["real"])
+            finally:
+                self._scalars = None
+            entry["graph"] = graph
+        host = entry["host"]
+        host[0] = 0.0 if alpha is None else alpha
+        host[1] = self.d_optimizer.next_step_size()
+        host[2] = self.g_optimizer.next_step_size()
+        entry["scal"].copy_(host, non_blocking=True)
+        entry["real"].copy_(real)
+        entry["graph"].replay()
+        self.actual_step += 1
+        return entry["out"]
+
+    def _step_body(self, real):
+        """The device work of one step on a batch resident in HBM."""
         D, G = self.discriminator, self.generator
-        real = D._to_device(real_images)
+        scal = self._scalars
         n = real.shape[0]
         batches = self._micro_batches(n)
 
@@ -618,7 +703,7 @@ class WGAN:
                 self.dist.wait_for(pending)
             ops.combine_grads(flat_f, flat_f, flat_r, cf, cr)
             D.bind_grads(0)
-            self.d_optimizer.apply_model_gradients(D)
+            self.d_optimizer.apply_model_gradients(D, None if scal is None else scal[1:2])
 
         # ---- metric block 0 ----
         real_sum = None
@@ -662,12 +747,11 @@ class WGAN:
         ops.combine_grads(flat_g, flat_g, None, cf, None)
         if self.dist is not None:
             self.dist.all_reduce(flat_g)
-        self.g_optimizer.apply_model_gradients(G)
+        self.g_optimizer.apply_model_gradients(G, None if scal is None else scal[2:3])
 
         # ---- metric block 1 ----
         m1 = self._metric_block(real, n, batches, real_sum)
 
-        self.actual_step += 1
         self.last_losses = {"d_loss": out_d[0], "g_loss": out_g[0]}
         return {"delta_0": m0[3], "cu_0": m0[1], "ci_0": m0[2], "delta_1": m1[3], "cu_1": m1[1], "ci_1": m1[2]}
 

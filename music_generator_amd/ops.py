@@ -442,6 +442,12 @@ def wgan_loss(sums, n_global, mode, out4, dfake, dreal, n_local):
 
 
 def adam_multi(p_table, n_table, off_table, g_flat, v_flat, blk_tensor, blk_start, nblocks, lr_t, beta2, eps):
+    """lr_t: a host float, or a 1-element device tensor read when the kernel runs (captured steps)."""
+    if isinstance(lr_t, torch.Tensor):
+        check(_lib().mgx_adam_multi_devlr(p_table.data_ptr(), n_table.data_ptr(), off_table.data_ptr(), _p(g_flat),
+                                          _p(v_flat), blk_tensor.data_ptr(), blk_start.data_ptr(), nblocks, _p(lr_t),
+                                          float(beta2), float(eps), K.stream_ptr()), "mgx_adam_multi_devlr")
+        return
     check(_lib().mgx_adam_multi(p_table.data_ptr(), n_table.data_ptr(), off_table.data_ptr(), _p(g_flat), _p(v_flat),
                                 blk_tensor.data_ptr(), blk_start.data_ptr(), nblocks, float(lr_t), float(beta2),
                                 float(eps), K.stream_ptr()), "mgx_adam_multi")
