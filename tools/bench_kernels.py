@@ -1,5 +1,5 @@
-"""Micro-benchmark of single layers through the Python layer objects (not collected by pytest).
-usage: python tests/bench_kernels.py conv3|conv3_128|conv2|gblock [reps]"""
+"""Micro-benchmark of single layers through the Python layer objects.
+usage: python tools/bench_kernels.py conv3|conv3_128|conv2|gblock [reps]"""
 import os, sys, time
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import numpy as np, torch

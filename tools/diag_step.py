@@ -1,7 +1,7 @@
-"""Diagnostic (not collected by pytest): per-tensor gradient errors of one train step vs the oracle."""
+"""Diagnostic: per-tensor gradient errors of one train step vs the oracle."""
 import sys, os
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
-sys.path.insert(0, os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "tests"))
 import numpy as np, torch
 import music_generator_amd as M
 from oracle import ref_step as R
