@@ -373,3 +373,42 @@ def test_evaluator_family_structure_and_inception_score():
     assert E.calculate_inception_score(p) == pytest.approx(RE.inception_score(p), rel=1e-12)
     assert E.calculate_inception_score(np.full((5, 9), 1 / 9.0)) == pytest.approx(1.0)
     assert E.calculate_inception_score(np.eye(9)) == pytest.approx(9.0, rel=1e-9)
+
+
+def test_directory_dataset_reader(tmp_path):
+    """trainer/dataset.py:213-239: nine class folders per resolution, (channels, frames) samples
+    reshaped as they are to (H, W, 2), one-hot labels, broken files skipped, five failures in a row
+    end a folder."""
+    from scipy.io import wavfile
+    from music_generator_amd import dataset
+    rng = np.random.default_rng(5)
+    h, w = 4, 750
+    base = tmp_path / "wav" / ("%d-%d" % (h, w))
+    clips = {}
+    for folder, count in ((1, 2), (3, 1)):
+        (base / str(folder)).mkdir(parents=True)
+        for i in range(count):
+            sig = rng.uniform(-1, 1, (h * w, 2)).astype(np.float32)          # (frames, channels) on disk
+            wavfile.write(str(base / str(folder) / ("%d.wav" % (i + 1))), w, sig)
+            clips[(folder, i)] = sig
+    (base / "1" / "3.wav").write_bytes(b"not a wav file")                    # skipped
+    wavfile.write(str(base / "3" / "0_short.wav"), w, np.zeros((10, 2), np.float32))   # wrong length: skipped
+    pcm = (rng.uniform(-1, 1, (h * w, 2)) * 32767).astype(np.int16)
+    (base / "9").mkdir()
+    wavfile.write(str(base / "9" / "1.wav"), w, pcm)
+    (base / "5").mkdir()
+    for i in range(6):
+        (base / "5" / ("%d.wav" % i)).write_bytes(b"junk")
+    wavfile.write(str(base / "5" / "z.wav"), w, clips[(1, 0)])               # after five failures: never reached
+    x, y = dataset.read_dataset((h, w), "wav", root=str(tmp_path))
+    assert x.shape == (4, h, w, 2) and x.dtype == np.float32 and y.shape == (4, 9)
+    assert y.argmax(axis=1).tolist() == [0, 0, 2, 8] and np.all(y.sum(axis=1) == 1)
+    assert np.array_equal(x[0], clips[(1, 0)].T.reshape(h, w, 2))            # audiofile layout, reshaped as is
+    assert np.array_equal(x[2], clips[(3, 0)].T.reshape(h, w, 2))
+    assert np.allclose(x[3], (pcm.astype(np.float32) / 32768.0).T.reshape(h, w, 2))
+    xi, _ = dataset.read_dataset((h, w), "wav", root=str(tmp_path), channels_first=False)
+    assert np.array_equal(xi[1], clips[(1, 1)].reshape(h, w, 2))
+    assert dataset.directory_provider(str(tmp_path))(h, w).shape == (4, h, w, 2)
+    assert dataset.read_dataset((8, 1500), "wav", root=str(tmp_path))[0].shape == (0, 8, 1500, 2)
+    with pytest.raises(NotImplementedError):
+        dataset.read_dataset((h, w), "mp3", root=str(tmp_path))
