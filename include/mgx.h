@@ -202,6 +202,13 @@ int mgx_softrect_bwd(const float* dy, const float* x, float* dx, int accumulate,
  * (trainer/evaluacion.py:97), whose outputs feed calculate_inception_score (trainer/utils.py:65-76). */
 int mgx_softmax_rows(const float* x, float* y, int64_t rows, int cols, void* stream);
 
+/* Fitting the evaluator (trainer/evaluacion.py:158-161, compile(optimizer="Adam",
+ * loss='categorical_crossentropy')): softmax probabilities, per-row loss -sum_c y log softmax(x)_c taken from
+ * the logits (as tf.keras does for the output of a Softmax op: no probability clipping) and (dx may be
+ * NULL) the gradient of the batch-mean loss with respect to the logits, (p - y)/rows. */
+int mgx_softmax_xent(const float* x, const float* onehot, float* prob, float* loss_rows, float* dx,
+                     int64_t rows, int cols, void* stream);
+
 /* Flatten + Dense(1) (models.py:339-340): y[i] = sum_e x[i,e]*w[e] + b.  Backward: dx[i,e] =
  * dy[i]*w[e] (if dx != NULL), dw[e] += sum_i dy[i]*x[i,e], db += sum_i dy[i] (if dw != NULL). */
 int mgx_dense1_fwd(const float* x, const float* w, const float* b, float* y, int64_t n, int64_t e, void* stream);
@@ -235,6 +242,12 @@ int mgx_combine_grads(float* out, const float* a, const float* b, const float* c
 int mgx_adam_multi(float* const* p, const int64_t* n, const int64_t* off, const float* g, float* v,
                    const int32_t* blk_tensor, const int64_t* blk_start, int64_t nblocks,
                    float lr_t, float beta2, float eps, void* stream);
+/* Adam with a first moment (keras' default beta_1 = 0.9, the optimiser of evaluacion.py:160):
+ *   m = beta1*m + (1-beta1)*g;  v = beta2*v + (1-beta2)*g*g;  p -= lr_t * m / (sqrt(v) + eps),
+ * lr_t = lr*sqrt(1-beta2^t)/(1-beta1^t) computed by the caller.  Tables as in mgx_adam_multi. */
+int mgx_adam_multi_m(float* const* p, const int64_t* n, const int64_t* off, const float* g, float* m, float* v,
+                     const int32_t* blk_tensor, const int64_t* blk_start, int64_t nblocks,
+                     float lr_t, float beta1, float beta2, float eps, void* stream);
 /* The same update with the step size lr_t = lr*sqrt(1-beta2^t) (keras OptimizerV2, the optimisers of
  * models.py:502-503) read from device memory at execution time: a train step captured once into a HIP
  * graph is replayed with a new t by rewriting that one float before the replay. */

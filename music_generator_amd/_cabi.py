@@ -92,6 +92,8 @@ PROTOTYPES = {
     "mgx_combine_grads": (_I, [_P, _P, _P, _P, _P, _I64, _P]),
     "mgx_wgan_loss": (_I, [_P, _I64, _I, _P, _P, _P, _I64, _P]),
     "mgx_adam_multi": (_I, [_P, _P, _P, _P, _P, _P, _P, _I64, _F, _F, _F, _P]),
+    "mgx_adam_multi_m": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I64, _F, _F, _F, _F, _P]),
+    "mgx_softmax_xent": (_I, [_P, _P, _P, _P, _P, _I64, _I, _P]),
     "mgx_adam_multi_devlr": (_I, [_P, _P, _P, _P, _P, _P, _P, _I64, _P, _F, _F, _P]),
 }
 

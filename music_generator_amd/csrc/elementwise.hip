@@ -229,6 +229,65 @@ __global__ __launch_bounds__(1024) void adam_multi_kernel(float* const* __restri
     }
 }
 
+// Adam with a first moment (keras' default beta_1 = 0.9, the evaluator's optimiser, evaluacion.py:160)
+__global__ __launch_bounds__(1024) void adam_multi_m_kernel(float* const* __restrict__ p, const int64_t* __restrict__ n,
+                                                            const int64_t* __restrict__ off, const float* __restrict__ g,
+                                                            float* __restrict__ m, float* __restrict__ v,
+                                                            const int32_t* __restrict__ blk_tensor,
+                                                            const int64_t* __restrict__ blk_start, float lr_t, float beta1,
+                                                            float beta2, float eps) {
+    const int t = blk_tensor[blockIdx.x];
+    const int64_t start = blk_start[blockIdx.x];
+    const int64_t cnt = n[t];
+    float* pp = p[t];
+    const float* gg = g + off[t];
+    float* mm = m + off[t];
+    float* vv = v + off[t];
+#pragma unroll
+    for (int k = 0; k < 4; ++k) {
+        const int64_t i = start + (int64_t)k * 1024 + threadIdx.x;
+        if (i < cnt) {
+            const float gi = gg[i];
+            const float mi = beta1 * mm[i] + (1.0f - beta1) * gi;
+            const float vi = beta2 * vv[i] + (1.0f - beta2) * gi * gi;
+            mm[i] = mi;
+            vv[i] = vi;
+            pp[i] -= lr_t * mi / (sqrtf(vi) + eps);
+        }
+    }
+}
+
+// Softmax + categorical cross-entropy of one batch (evaluacion.py:160).  tf.keras evaluates
+// categorical_crossentropy on the output of a Softmax op from that op's logits
+// (softmax_cross_entropy_with_logits), so there is no probability clipping: per row probabilities,
+// loss_rows[r] = -sum_c y (x - max - log sum exp) and the gradient of the batch-mean loss with
+// respect to the logits, (p - y) / rows.
+__global__ __launch_bounds__(64) void softmax_xent_kernel(const float* __restrict__ x, const float* __restrict__ onehot,
+                                                          float* __restrict__ prob, float* __restrict__ loss_rows,
+                                                          float* __restrict__ dx, long rows, int cols) {
+    const int lane = threadIdx.x;
+    const float inv_rows = 1.0f / (float)rows;
+    for (long r = blockIdx.x; r < rows; r += gridDim.x) {
+        const float* xr = x + r * cols;
+        float mx = -INFINITY;
+        for (int c = lane; c < cols; c += 64) mx = fmaxf(mx, xr[c]);
+        for (int o = 32; o > 0; o >>= 1) mx = fmaxf(mx, __shfl_xor(mx, o));
+        float sum = 0.f;
+        for (int c = lane; c < cols; c += 64) sum += __expf(xr[c] - mx);
+        for (int o = 32; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+        const float inv = 1.f / sum, lse = mx + logf(sum);
+        float loss = 0.f;
+        for (int c = lane; c < cols; c += 64) {
+            const float pc = __expf(xr[c] - mx) * inv, yc = onehot[r * cols + c];
+            prob[r * cols + c] = pc;
+            if (dx) dx[r * cols + c] = (pc - yc) * inv_rows;
+            loss -= yc * (xr[c] - lse);
+        }
+        for (int o = 32; o > 0; o >>= 1) loss += __shfl_xor(loss, o);
+        if (lane == 0) loss_rows[r] = loss;
+    }
+}
+
 // Row softmax (the Dense(9, activation='softmax') head of the evaluator, evaluacion.py:97): one
 // wavefront per row, three passes over the row (max, sum of exp, write) with wave reductions.
 __global__ __launch_bounds__(64) void softmax_rows_kernel(const float* __restrict__ x, float* __restrict__ y, long rows,
@@ -322,6 +381,25 @@ extern "C" int mgx_weighted_sum_bwd(const float* dy, const float* a, const float
                        acc_b, part, (long)n);
     if (dalpha)
         hipLaunchKernelGGL(finish_sum_kernel, dim3(1), dim3(64), 0, (hipStream_t)stream, part, (int)grid, dalpha);
+    return mgx_launch_status();
+}
+
+extern "C" int mgx_adam_multi_m(float* const* p, const int64_t* n, const int64_t* off, const float* g, float* m,
+                                float* v, const int32_t* blk_tensor, const int64_t* blk_start, int64_t nblocks,
+                                float lr_t, float beta1, float beta2, float eps, void* stream) {
+    if (!p || !n || !off || !g || !m || !v || !blk_tensor || !blk_start || nblocks <= 0 || nblocks > 0x7fffffffL)
+        return MGX_ERR_ARG;
+    hipLaunchKernelGGL(adam_multi_m_kernel, dim3((unsigned)nblocks), dim3(1024), 0, (hipStream_t)stream, p, n, off, g,
+                       m, v, blk_tensor, blk_start, lr_t, beta1, beta2, eps);
+    return mgx_launch_status();
+}
+
+extern "C" int mgx_softmax_xent(const float* x, const float* onehot, float* prob, float* loss_rows, float* dx,
+                                int64_t rows, int cols, void* stream) {
+    if (!x || !onehot || !prob || !loss_rows || rows <= 0 || cols <= 0) return MGX_ERR_ARG;
+    const unsigned grid = (unsigned)(rows < 65536 ? rows : 65536);
+    hipLaunchKernelGGL(softmax_xent_kernel, dim3(grid), dim3(64), 0, (hipStream_t)stream, x, onehot, prob, loss_rows, dx,
+                       (long)rows, cols);
     return mgx_launch_status();
 }
 

@@ -4,13 +4,17 @@ trainer/utils.py:98, 121).
 
 The evaluator is a progressive family like the discriminator, but purely linear: 128-channel
 convolutions without activations and a Dense(9, softmax) classifier head.  Its 128 -> 128
-convolutions run on the library's general contraction kernel.  Fitting the evaluator
-(load_evaluator's compile/fit with categorical cross-entropy, evaluacion.py:158-161) is not part of
-this package: weights come from `Model.load_weights` / `set_weights_dict`.
+convolutions run on the library's general contraction kernel.  `load_evaluator` is the
+download=False branch of evaluacion.py:114-166: fit the model of one resolution on (clips, one-hot
+labels) with Adam (keras defaults) and categorical cross-entropy; the cloud download / upload of
+the .h5 file is replaced by `Model.save` / `load_weights`.
 """
 from __future__ import annotations
 
+from typing import Dict, List, Optional
+
 import numpy as np
+import torch
 
 from . import backend as K
 from . import ops
@@ -19,18 +23,17 @@ from .layers import Conv2D, Dense, Flatten
 
 
 class SoftmaxDense(Dense):
-    """Dense(units, activation='softmax') on a flattened input (evaluacion.py:97)."""
+    """Dense(units, activation='softmax') on a flattened input (evaluacion.py:97).  With a tape
+    the layer returns its LOGITS: the fitting loop pairs them with the fused softmax +
+    cross-entropy kernel, whose logit gradient is what backward() receives."""
 
     def forward(self, xs, save, act_alpha: float = 0.0):
+        logits, saved = super().forward(xs, save, 0.0)
         if save:
-            raise NotImplementedError("the evaluator head is inference-only")
-        logits, _ = super().forward(xs, False, 0.0)
+            return logits, saved
         y = K.empty(logits.shape)
         ops.softmax_rows(logits.contiguous(), y)
         return y, None
-
-    def backward(self, saved, dy, need, existing, wgrad):
-        raise NotImplementedError("the evaluator head is inference-only")
 
 
 def _conv(t, ksize, **kw):
@@ -82,3 +85,80 @@ def calculate_inception_score(p_yx, eps=1e-16):
     p_y = p_yx.mean(axis=0, keepdims=True)
     kl = p_yx * (np.log(p_yx + eps) - np.log(p_y + eps))
     return float(np.exp(kl.sum(axis=1).mean()))
+
+
+# evaluacion.py:130-157: batch size and epochs per resolution
+FIT_TABLE = {4: (64, 10), 8: (32, 20), 16: (16, 30), 32: (8, 40), 64: (4, 50), 128: (2, 60), 256: (2, 70)}
+
+
+def labels_to_device(y) -> torch.Tensor:
+    """One-hot labels (n, classes) as a contiguous float32 device tensor."""
+    t = y if isinstance(y, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(y, dtype=np.float32))
+    return t.to(device=K.device(), dtype=torch.float32).contiguous()
+
+
+def evaluate(model, x, y, batch_size: int = 32) -> Dict[str, float]:
+    """Mean categorical cross-entropy and accuracy over (x, y) - keras' evaluate / validation pass."""
+    n = x.shape[0]
+    loss, hits = 0.0, 0
+    for i in range(0, n, batch_size):
+        xb = model._to_device(x[i:i + batch_size])
+        yb = labels_to_device(y[i:i + batch_size])
+        logits, _ = model.forward(xb, save=True)          # with a tape the head returns logits
+        prob, rows = K.empty(logits.shape), K.empty((logits.shape[0],))
+        ops.softmax_xent(logits.contiguous(), yb, prob, rows, None)
+        loss += float(rows.sum())
+        hits += int((prob.argmax(dim=1) == yb.argmax(dim=1)).sum())
+    return {"loss": loss / n, "accuracy": hits / n}
+
+
+def fit_evaluator(model, x, y, epochs: int, batch_size: int, optimizer=None, validation_data=None,
+                  shuffle_seed: int = 0, verbose: int = 0) -> Dict[str, List[float]]:
+    """model.compile(optimizer="Adam", loss='categorical_crossentropy', metrics=["accuracy"]) +
+    model.fit(X, y, epochs, batch_size, validation_data) of evaluacion.py:160-161.  Returns the
+    history: per epoch the sample-weighted mean of the batch losses / accuracies (and val_*)."""
+    from .models import Adam
+    opt = optimizer or Adam()                              # keras defaults: 1e-3, 0.9, 0.999, 1e-7
+    n = x.shape[0]
+    rng = np.random.default_rng(shuffle_seed)
+    hist: Dict[str, List[float]] = {"loss": [], "accuracy": []}
+    y = np.ascontiguousarray(y, dtype=np.float32)
+    for epoch in range(epochs):
+        order = rng.permutation(n)
+        loss_sum = torch.zeros((), dtype=torch.float32, device=K.device())
+        hits = torch.zeros((), dtype=torch.int64, device=K.device())
+        for i in range(0, n, batch_size):
+            idx = order[i:i + batch_size]
+            xb, yb = model._to_device(x[idx]), labels_to_device(y[idx])
+            flat = model.bind_grads(0)
+            flat.zero_()
+            logits, tape = model.forward(xb, save=True)
+            prob, rows, dlogits = K.empty(logits.shape), K.empty((logits.shape[0],)), K.empty(logits.shape)
+            ops.softmax_xent(logits.contiguous(), yb, prob, rows, dlogits)
+            model.backward(tape, dlogits, need_input_grad=False)
+            opt.apply_model_gradients(model)
+            loss_sum += rows.sum()
+            hits += (prob.argmax(dim=1) == yb.argmax(dim=1)).sum()
+        hist["loss"].append(float(loss_sum) / n)
+        hist["accuracy"].append(int(hits) / n)
+        if validation_data is not None:
+            val = evaluate(model, validation_data[0], validation_data[1], batch_size)
+            hist.setdefault("val_loss", []).append(val["loss"])
+            hist.setdefault("val_accuracy", []).append(val["accuracy"])
+        if verbose:
+            print("epoch %d/%d " % (epoch + 1, epochs) + " ".join("%s=%.4f" % (k, v[-1]) for k, v in hist.items()))
+    return hist
+
+
+def load_evaluator(dimension, train_dataset, epochs: Optional[int] = None, n_blocks: int = 7, verbose: int = 0):
+    """evaluacion.py:114-166 with download=False: build the family, pick the model of `dimension`
+    (H, W), fit it on train_dataset = (X, one-hot y) with the batch size / epochs of the
+    reference's table, validating on the training set as the reference does.  Returns the model
+    (history in `model.fit_history`)."""
+    batch_size, table_epochs = FIT_TABLE[int(dimension[0])]
+    stage = int(dimension[0]).bit_length() - 3            # 4 -> 0, 8 -> 1, ...
+    model = define_evaluator(max(n_blocks, stage + 1))[stage]
+    x, y = train_dataset
+    model.fit_history = fit_evaluator(model, x, y, table_epochs if epochs is None else epochs, batch_size,
+                                      validation_data=(x, y), verbose=verbose)
+    return model

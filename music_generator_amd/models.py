@@ -392,15 +392,14 @@ def generator_loss(fake_logits, real_logits):
 # optimiser
 # --------------------------------------------------------------------------------------------
 class Adam:
-    """keras.optimizers.Adam as configured by define_composite (models.py:502-503): the update of
-    tf.keras OptimizerV2 (non-amsgrad) with beta_1 = 0, so the first moment equals the gradient.
+    """keras.optimizers.Adam, the update of tf.keras OptimizerV2 (non-amsgrad).  As configured by
+    define_composite (models.py:502-503) beta_1 = 0, so the first moment equals the gradient and is
+    not stored; any other beta_1 (keras' default 0.9, the evaluator's optimiser) keeps one.
     One fused multi-tensor kernel updates every variable of a model."""
 
     def __init__(self, lr=0.001, beta_1=0.9, beta_2=0.999, epsilon=1e-7, learning_rate=None):
         self.lr = float(learning_rate if learning_rate is not None else lr)
         self.beta_1, self.beta_2, self.epsilon = float(beta_1), float(beta_2), float(epsilon)
-        if self.beta_1 != 0.0:
-            raise NotImplementedError("the fused Adam kernel implements beta_1 = 0 (the reference's setting)")
         self.iterations = 0
         self._state = None
 
@@ -414,16 +413,16 @@ class Adam:
             for start in range(0, n, 4096):
                 blk_t.append(i); blk_s.append(start)
         self._state = dict(
-            model=model, v=torch.zeros_like(flat),
+            model=model, v=torch.zeros_like(flat), m=torch.zeros_like(flat) if self.beta_1 != 0.0 else None,
             p=torch.tensor(ptrs, dtype=torch.int64, device=dev), n=torch.tensor(ns, dtype=torch.int64, device=dev),
             off=torch.tensor(offs, dtype=torch.int64, device=dev),
             blk_t=torch.tensor(blk_t, dtype=torch.int32, device=dev),
             blk_s=torch.tensor(blk_s, dtype=torch.int64, device=dev), nblocks=len(blk_t))
 
     def next_step_size(self) -> float:
-        """Count one more update and return its lr_t = lr * sqrt(1 - beta_2^t)."""
+        """Count one more update and return its lr_t = lr * sqrt(1 - beta_2^t) / (1 - beta_1^t)."""
         self.iterations += 1
-        return self.lr * math.sqrt(1.0 - self.beta_2 ** self.iterations)
+        return self.lr * math.sqrt(1.0 - self.beta_2 ** self.iterations) / (1.0 - self.beta_1 ** self.iterations)
 
     def apply_model_gradients(self, model: Model, lr_dev: Optional[torch.Tensor] = None):
         """Adam.apply_gradients(zip(grads, model.trainable_variables)) for gradients held in the
@@ -435,6 +434,12 @@ class Adam:
         st = self._state
         if st["model"] is not model:
             raise RuntimeError("an Adam instance is bound to the first model it updates")
+        if st["m"] is not None:
+            if lr_dev is not None:
+                raise NotImplementedError("device-resident step sizes are implemented for beta_1 = 0")
+            ops.adam_multi_m(st["p"], st["n"], st["off"], model.bind_grads(), st["m"], st["v"], st["blk_t"],
+                             st["blk_s"], st["nblocks"], self.next_step_size(), self.beta_1, self.beta_2, self.epsilon)
+            return
         lr_t = lr_dev if lr_dev is not None else self.next_step_size()
         ops.adam_multi(st["p"], st["n"], st["off"], model.bind_grads(), st["v"], st["blk_t"], st["blk_s"],
                        st["nblocks"], lr_t, self.beta_2, self.epsilon)

@@ -382,6 +382,21 @@ def mbstd_bwd(dy, x, dx, n, h, w, c):
           "mgx_mbstd_bwd")
 
 
+def softmax_xent(logits, onehot, prob, loss_rows, dlogits=None):
+    if logits.dim() != 2 or onehot.shape != logits.shape or prob.shape != logits.shape \
+            or loss_rows.numel() != logits.shape[0] or (dlogits is not None and dlogits.shape != logits.shape):
+        raise MgxError("softmax_xent: shape mismatch")
+    check(_lib().mgx_softmax_xent(_p(logits), _p(onehot), _p(prob), _p(loss_rows), _p(dlogits), logits.shape[0],
+                                  logits.shape[1], K.stream_ptr()), "mgx_softmax_xent")
+
+
+def adam_multi_m(p_table, n_table, off_table, g_flat, m_flat, v_flat, blk_tensor, blk_start, nblocks, lr_t, beta1,
+                 beta2, eps):
+    check(_lib().mgx_adam_multi_m(p_table.data_ptr(), n_table.data_ptr(), off_table.data_ptr(), _p(g_flat), _p(m_flat),
+                                  _p(v_flat), blk_tensor.data_ptr(), blk_start.data_ptr(), nblocks, float(lr_t),
+                                  float(beta1), float(beta2), float(eps), K.stream_ptr()), "mgx_adam_multi_m")
+
+
 def softmax_rows(x, y):
     if x.dim() != 2 or x.shape != y.shape:
         raise MgxError("softmax_rows: expected two (rows, cols) tensors of one shape")

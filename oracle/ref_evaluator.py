@@ -70,3 +70,37 @@ def inception_score(p_yx, eps=1e-16) -> float:
     for i in range(n):
         total += sum(p[i, j] * (np.log(p[i, j] + eps) - np.log(p_y[j] + eps)) for j in range(c))
     return float(np.exp(total / n))
+
+
+def fit_steps(stage: int, kernels, biases, dense_k, dense_b, batches, lr=1e-3, beta_1=0.9, beta_2=0.999, eps=1e-7):
+    """Batches of (x, one-hot y) through compile(optimizer="Adam", loss='categorical_crossentropy')
+    + fit (trainer/evaluacion.py:160-161) in float64 with autograd: mean over the batch of
+    -sum_c y log softmax(logits)_c (tf.keras takes the loss of a Softmax output from its logits,
+    without clipping), keras' Adam update with bias-corrected step size
+    lr*sqrt(1-beta_2^t)/(1-beta_1^t).  -> (losses, gradients of the LAST batch, parameters after
+    the last update), parameter order: kernel0, bias0, kernel1, ..., dense kernel, dense bias."""
+    specs = conv_specs(stage)
+    params = []
+    for k, b in zip(kernels, biases):
+        params += [torch.tensor(np.asarray(k), dtype=torch.float64, requires_grad=True),
+                   torch.tensor(np.asarray(b), dtype=torch.float64, requires_grad=True)]
+    params += [torch.tensor(np.asarray(dense_k), dtype=torch.float64, requires_grad=True),
+               torch.tensor(np.asarray(dense_b), dtype=torch.float64, requires_grad=True)]
+    m = [torch.zeros_like(p) for p in params]
+    v = [torch.zeros_like(p) for p in params]
+    losses, grads = [], None
+    for t, (x, y) in enumerate(batches, start=1):
+        h = torch.as_tensor(np.asarray(x), dtype=torch.float64)
+        for i, (kh, kw, s, pad) in enumerate(specs):
+            h = conv_nhwc(h, params[2 * i], params[2 * i + 1], s, pad)
+        logits = h.reshape(h.shape[0], -1) @ params[-2] + params[-1]
+        loss = -(torch.as_tensor(np.asarray(y), dtype=torch.float64) * torch.log_softmax(logits, dim=1)).sum(dim=1).mean()
+        grads = torch.autograd.grad(loss, params)
+        losses.append(float(loss.detach()))
+        lr_t = lr * np.sqrt(1 - beta_2 ** t) / (1 - beta_1 ** t)
+        with torch.no_grad():
+            for q, g, mq, vq in zip(params, grads, m, v):
+                mq.mul_(beta_1).add_((1 - beta_1) * g)
+                vq.mul_(beta_2).add_((1 - beta_2) * g * g)
+                q.sub_(lr_t * mq / (vq.sqrt() + eps))
+    return losses, [g.numpy() for g in grads], [q.detach().numpy() for q in params]

@@ -299,3 +299,62 @@ def test_softmax_rows_wide_and_saturated():
     assert np.abs(y.cpu().numpy() - want).max() < 2e-6
     with pytest.raises(ops.MgxError):
         ops.softmax_rows(xd, torch.empty((37, 199), device="cuda"))
+
+
+def test_evaluator_fit_matches_oracle():
+    """Two fitting steps of the stage-0 evaluator (trainer/evaluacion.py:158-161: Adam with a first
+    moment, categorical cross-entropy on the softmax head) against float64 autograd: losses rel
+    1e-5, gradients of the second batch rel-L2 1e-4, parameters after the second update abs 2e-7
+    = lr/50 for 99.99 % of every tensor's entries and 2.1 lr for all (the first Adam updates are
+    ~lr * sign(g): where a gradient of either step is ~0, float32 noise decides the direction).
+    lr = 1e-5 here: with keras' default 1e-3 one sign-like step moves this 10-layer linear network
+    far enough for float32 and float64 trajectories to part."""
+    import music_generator_amd as M
+    from music_generator_amd import evaluacion as E, ops
+    from music_generator_amd import backend as K
+    from oracle import ref_evaluator as RE
+    M.clear_session()
+    model = E.define_evaluator(1)[0]
+    rng = np.random.default_rng(77)
+    convs = [l for l in model.layers if isinstance(l, M.layers.Conv2D)]
+    kernels, biases = [], []
+    for l in convs:
+        fan_in = l.kernel_size[0] * l.kernel_size[1] * l.kernel.shape[2]
+        k = (rng.standard_normal(l.kernel.shape) / np.sqrt(fan_in)).astype(np.float32)
+        b = (0.05 * rng.standard_normal(l.bias.shape)).astype(np.float32)
+        l.kernel.assign(k), l.bias.assign(b)
+        kernels.append(k), biases.append(b)
+    head = model.layers[-1]
+    dk = (rng.standard_normal(head.kernel.shape) / np.sqrt(head.kernel.shape[0])).astype(np.float32)
+    db = (0.1 * rng.standard_normal(head.bias.shape)).astype(np.float32)
+    head.kernel.assign(dk), head.bias.assign(db)
+    batches = []
+    for _ in range(2):
+        x = rng.uniform(-1, 1, (4, 4, 750, 2)).astype(np.float32)
+        y = np.eye(9, dtype=np.float32)[rng.integers(0, 9, 4)]
+        batches.append((x, y))
+    opt = M.Adam(lr=1e-5)
+    losses = []
+    for x, y in batches:
+        xb, yb = model._to_device(x), E.labels_to_device(y)
+        flat = model.bind_grads(0)
+        flat.zero_()
+        logits, tape = model.forward(xb, save=True)
+        prob, rows, dlogits = K.empty(logits.shape), K.empty((4,)), K.empty(logits.shape)
+        ops.softmax_xent(logits.contiguous(), yb, prob, rows, dlogits)
+        model.backward(tape, dlogits, need_input_grad=False)
+        grads = [v.grad.cpu().numpy().reshape(v.shape).copy() for l in convs + [head] for v in (l.kernel, l.bias)]
+        opt.apply_model_gradients(model)
+        losses.append(float(rows.mean()))
+    ref_losses, ref_grads, ref_params = RE.fit_steps(0, kernels, biases, dk, db, batches, lr=1e-5)
+    assert losses == pytest.approx(ref_losses, rel=1e-5)
+    params = [v.numpy() for l in convs + [head] for v in (l.kernel, l.bias)]
+    for g, rg, p, rp in zip(grads, ref_grads, params, ref_params):
+        assert rel_l2(g, rg) < 1e-4, rel_l2(g, rg)
+        diff = np.abs(p - rp)
+        assert np.quantile(diff, 0.9999) < 2e-7 and diff.max() < 2.1e-5, (np.quantile(diff, 0.9999), diff.max())
+    # the fitting loop itself: history shapes, validation on the training set, loss going down
+    x = np.concatenate([b[0] for b in batches]); y = np.concatenate([b[1] for b in batches])
+    hist = E.fit_evaluator(model, x, y, epochs=3, batch_size=4, optimizer=M.Adam(lr=1e-5), validation_data=(x, y))
+    assert [len(hist[k]) for k in ("loss", "accuracy", "val_loss", "val_accuracy")] == [3, 3, 3, 3]
+    assert np.isfinite(hist["loss"]).all() and hist["val_loss"][-1] < hist["val_loss"][0]
