@@ -1,3 +1,6 @@
+#!/bin/bash
+# Eager step against the HIP-graph replay (bench.py --graph) at the reference's batch sizes
+# (trainer/task.py:186): stage and batch per line; prints the head of each bench line.
 set -e
 for cfg in "0 16" "1 8" "2 4" "3 2" "4 2"; do
   set -- $cfg
