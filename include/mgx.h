@@ -76,12 +76,14 @@ int mgx_conv_wgrad_f32(const mgx_conv_desc* d, const float* x, const float* dy, 
                        float* dw, float* dbias, void* workspace, int64_t workspace_bytes, void* stream);
 
 /* Which kernel family serves the contraction: 0 = generic implicit GEMM, 1 = LDS tile kernels
- * (stride-1 'same' 3x3 / 2x2 convs over 32-channel slices), 2 = vector-ALU 1x1 kernel for 2-channel
+ * (stride-1 'same' 4x4 / 3x3 / 2x2 / 1x1 convs over 32-channel slices), 2 = vector-ALU 1x1 kernel for 2-channel
  * inputs (forward only, when no input multiplier is passed), 3 = Winograd F(2x2,3x3) kernel (3x3
  * 'same' convolutions with 32 output channels, forward or data-gradient weight layout, and their
  * weight gradients; with an input multiplier the forward / data-gradient form only for 32 input
  * channels and no activation, then also with 128 output channels; the tile kernels otherwise;
- * MGX_WINOGRAD=0 in the environment turns it off).  `wgrad` = 0 asks about mgx_conv_gemm_f32
+ * MGX_WINOGRAD=0 in the environment turns it off), 4 = Dense-chain GEMM with the weight matrix in LDS
+ * (1x1, 64 / 128 / 256 channels on both sides, no multiplier, activation or accumulation: the
+ * stage-0 generator's Dense layers and their data-gradients).  `wgrad` = 0 asks about mgx_conv_gemm_f32
  * without an input multiplier, 2 about mgx_conv_gemm_f32 with one, 1 about mgx_conv_wgrad_f32.
  * d->act_alpha is taken into account.  No counterpart in the reference: it lets a caller label its
  * timings with the kernel that actually ran. */

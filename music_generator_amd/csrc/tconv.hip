@@ -232,6 +232,7 @@ bool mgx_pointwise_to2_applicable(const mgx_conv_desc& d);
 bool mgx_wconv_enabled();                                  // conv_gemm.hip
 bool mgx_wconv_applicable(const mgx_conv_desc& d, bool mul);   // wconv.hip
 bool mgx_wwgrad_applicable(const mgx_conv_desc& d);            // wwgrad.hip
+bool mgx_pgemm_applicable(const mgx_conv_desc& d, bool mul);   // pgemm.hip
 
 extern "C" int mgx_conv_route(const mgx_conv_desc* d, int wgrad) {
     if (!d) return 0;
@@ -242,7 +243,8 @@ extern "C" int mgx_conv_route(const mgx_conv_desc* d, int wgrad) {
     if (mgx_wconv_enabled() && mgx_wconv_applicable(*d, wgrad == 2)) return 3;
     if (mgx_tconv_applicable(*d)) return 1;
     if (mgx_pointwise_to2_applicable(*d)) return 2;
-    return mgx_pointwise2_applicable(*d) && wgrad == 0 ? 2 : 0;
+    if (mgx_pointwise2_applicable(*d) && wgrad == 0) return 2;
+    return mgx_pgemm_applicable(*d, wgrad == 2) ? 4 : 0;
 }
 
 long mgx_twgrad_splits(const mgx_conv_desc& d) {

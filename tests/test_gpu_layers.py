@@ -134,6 +134,14 @@ def test_dense(ci, co):
     _check(lambda t: L.Dense(co)(t), lambda x, wt: R.dense(x, wt["kernel"], wt["bias"]), (3, 45, ci), 2)
 
 
+@pytest.mark.parametrize("ci,co", [(64, 128), (128, 64), (256, 128)])
+def test_dense_many_rows(ci, co):
+    """67 200 rows = 525 row tiles of 128: every workgroup of the LDS-weight GEMM kernel walks two or
+    three tiles (the A operands of the next tile are loaded during the current one), forward and
+    data-gradient."""
+    _check(lambda t: L.Dense(co)(t), lambda x, wt: R.dense(x, wt["kernel"], wt["bias"]), (4, 4200, ci), 4)
+
+
 def test_dense1_with_static_opt_tanh():
     def build(t):
         return M.StaticOptTanh(alpha=5.0)(L.Dense(1)(L.Flatten()(t)))
