@@ -168,7 +168,8 @@ __global__ __launch_bounds__(256) void conv_gemm_kernel(mgx_conv_desc d, const f
     }
 
     // ---- epilogue: bias, activation, depth-to-space store ----
-    const bool scatter = (d.dkh * d.dkw) != 1;
+    // with dkh == 1 the dkw x cout columns of a row are contiguous in the output: no scatter needed
+    const bool scatter = d.dkh != 1;
     const float inv_alpha = d.act_alpha > 0.f ? 1.0f / d.act_alpha : 0.f;
     const long out_w = (long)d.wout * d.dkw;
 #pragma unroll
