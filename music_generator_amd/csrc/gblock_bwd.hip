@@ -264,10 +264,22 @@ template <int TA, int TB>
 __global__ __launch_bounds__(256, 1) void gblock_wgrad_kernel(const float* __restrict__ act,
                                                               const float* __restrict__ delta, GJobs jobs, int job0,
                                                               float* __restrict__ ws, long ntiles) {
-    const GJob jb = jobs.j[job0 + blockIdx.y];
+    // Jobs of one launch share operand rows (the same activation tile meets several gradient tiles
+    // and vice versa) and walk the position tiles at the same pace.  Workgroups are handed to the 8
+    // XCDs round-robin by linear id, so when the grid allows it the ids are re-mapped to put all
+    // jobs of one slab index on one XCD: the shared rows are then read from HBM once per XCD-local
+    // L2 instead of once per job.  Slabs are addressed by (job, split): the sums do not change.
+    int xb = blockIdx.x, jobi = blockIdx.y;
+    if ((gridDim.x & 7) == 0) {
+        const unsigned lin = blockIdx.x + blockIdx.y * gridDim.x;
+        const unsigned q = lin >> 3;
+        jobi = (int)(q % gridDim.y);
+        xb = (int)((q / gridDim.y) * 8 + (lin & 7));
+    }
+    const GJob jb = jobs.j[job0 + jobi];
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int i = lane & 31, h = lane >> 5;
-    const long split = (long)blockIdx.x * 4 + wv, nw = (long)gridDim.x * 4;
+    const long split = (long)xb * 4 + wv, nw = (long)gridDim.x * 4;
     f32x16 acc[TA][TB];
     float bs[TB];
 #pragma unroll
@@ -460,6 +472,7 @@ int grid_x(long ntiles, const ShapeRun& run) {
     long x = (ntiles + 3) / 4;
     long cap = (256L * run.wg_per_cu) / run.njobs;
     if (cap > 256) cap = 256;
+    cap &= ~7L;         // a multiple of 8 workgroups per job: lets the kernel keep a slab's jobs on one XCD
     if (x > cap) x = cap;
     return (int)(x < 1 ? 1 : x);
 }
