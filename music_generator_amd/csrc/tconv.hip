@@ -120,8 +120,16 @@ __global__ __launch_bounds__(256, KH * KW == 16 ? 1 : 2) void twgrad_kernel(mgx_
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int r = lane & 31, h = lane >> 5;
     const int H = d.hin, W = d.win;
-    const int kc = blockIdx.y;
+    // the input chunks of a tile share its output-gradient tile: keep them on one XCD (workgroups go
+    // to the XCDs round-robin by linear id); slabs are addressed by (chunk, split), sums unchanged
+    unsigned bx = blockIdx.x;
+    int kc = blockIdx.y;
     const int kchunks = d.cin / 32;
+    if (gridDim.y > 1 && (gridDim.x & 7) == 0) {
+        const unsigned lin = blockIdx.x + blockIdx.y * gridDim.x, q = lin >> 3;
+        kc = (int)(q % gridDim.y);
+        bx = (q / gridDim.y) * 8 + (lin & 7);
+    }
 
     f32x16 acc[TAPS];
 #pragma unroll
@@ -130,7 +138,7 @@ __global__ __launch_bounds__(256, KH * KW == 16 ? 1 : 2) void twgrad_kernel(mgx_
         for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
     float bsum = 0.f;
 
-    for (long t = blockIdx.x; t < ntiles; t += gridDim.x) {
+    for (long t = bx; t < ntiles; t += gridDim.x) {
         const Tile q = decode_tile(t, tiles_h, tiles_w, RT);
         __syncthreads();
         stage_tile<IH, IW, false>(xl, x, nullptr, q.img, q.h0 - d.pt, q.w0 - d.pl, H, W, d.cin, kc * 32);
@@ -155,7 +163,7 @@ __global__ __launch_bounds__(256, KH * KW == 16 ? 1 : 2) void twgrad_kernel(mgx_
     }
     // slabs: partial[((split*tiles_total + tile)*16 + reg)*64 + lane], split = (wg, wave),
     // tile = tap*kchunks + kc (one 32-column tile)
-    const long split = (long)blockIdx.x * 4 + wv;
+    const long split = (long)bx * 4 + wv;
     const long tiles_total = (long)TAPS * kchunks;
 #pragma unroll
     for (int t = 0; t < TAPS; ++t) {

@@ -46,14 +46,24 @@ __global__ __launch_bounds__(256, 1) void wino3_wgrad_kernel(mgx_conv_desc d, co
     const int lane = tid & 63, wv = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 31, h = lane >> 5;
     const int H = d.hin, W = d.win, cin = d.cin;
-    const int kc = blockIdx.y, kchunks = cin / 32;
+    // The cin/32 input chunks of a tile share its output-gradient tile.  Workgroups go to the 8 XCDs
+    // round-robin by linear id: re-map the ids so that the chunks of one tile index run on one XCD
+    // and find that tile in its L2.  Slabs are addressed by (chunk, split): the sums do not change.
+    unsigned bx = blockIdx.x;
+    int kc = blockIdx.y;
+    const int kchunks = cin / 32;
+    if (gridDim.y > 1 && (gridDim.x & 7) == 0) {
+        const unsigned lin = blockIdx.x + blockIdx.y * gridDim.x, q = lin >> 3;
+        kc = (int)(q % gridDim.y);
+        bx = (q / gridDim.y) * 8 + (lin & 7);
+    }
     const bool do_bias = bpartial != nullptr && kc == 0;
 
     // ---- tile walk in scalar registers ----
     GTile dstep, cur;
     {
         const unsigned per_img = (unsigned)(tiles_h * tiles_w);
-        const unsigned g = gridDim.x, b = blockIdx.x;
+        const unsigned g = gridDim.x, b = bx;
         dstep.img = (int)(g / per_img);
         unsigned rem = g - (unsigned)dstep.img * per_img;
         dstep.th = (int)(rem / (unsigned)tiles_w);
@@ -124,7 +134,7 @@ __global__ __launch_bounds__(256, 1) void wino3_wgrad_kernel(mgx_conv_desc d, co
         for (int i = 0; i < 16; ++i) acc[p][i] = 0.f;
     f32x2 bs2 = {0.f, 0.f};
 
-    long t = blockIdx.x;
+    long t = bx;
     if (t < ntiles) {
         stage_load(cur);
         stage_store(0);
@@ -221,7 +231,7 @@ __global__ __launch_bounds__(256, 1) void wino3_wgrad_kernel(mgx_conv_desc d, co
     // slabs: partial[((split * tiles_total + tile) * 16 + reg) * 64 + lane], split = (workgroup, wave),
     // tile = position * kchunks + kc
     asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 7" ::: "memory");
-    const long split = (long)blockIdx.x * 4 + wv;
+    const long split = (long)bx * 4 + wv;
     const long tiles_total = 16L * kchunks;
 #pragma unroll
     for (int p = 0; p < 16; ++p) {
