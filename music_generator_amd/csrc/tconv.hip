@@ -107,7 +107,9 @@ constexpr int twgrad_lds_bytes() { return ((RT + KH - 1) * (TW + KW - 1) + RT * 
 
 // A 4x4 kernel keeps 16 accumulator tiles = all 256 accumulation registers of a wave: one wave per
 // SIMD, MFMAs through the asm form that pins the accumulators there.
-template <int KH, int KW, int RT>
+// NCH > 1: the output gradient has NCH 32-channel chunks (the 1x1 convolution 32 -> 128); they are
+// staged one after the other against the same staged input tile, one accumulator tile each.
+template <int KH, int KW, int RT, int NCH = 1>
 __global__ __launch_bounds__(256, KH * KW == 16 ? 1 : 2) void twgrad_kernel(mgx_conv_desc d, const float* __restrict__ x,
                                                         const float* __restrict__ dy,
                                                         const float* __restrict__ dymul, float* __restrict__ partial,
@@ -131,47 +133,58 @@ __global__ __launch_bounds__(256, KH * KW == 16 ? 1 : 2) void twgrad_kernel(mgx_
         bx = (q / gridDim.y) * 8 + (lin & 7);
     }
 
-    f32x16 acc[TAPS];
+    f32x16 acc[TAPS * NCH];
 #pragma unroll
-    for (int t = 0; t < TAPS; ++t)
+    for (int t = 0; t < TAPS * NCH; ++t)
 #pragma unroll
         for (int i = 0; i < 16; ++i) acc[t][i] = 0.f;
-    float bsum = 0.f;
+    float bsum[NCH];
+#pragma unroll
+    for (int nc = 0; nc < NCH; ++nc) bsum[nc] = 0.f;
 
     for (long t = bx; t < ntiles; t += gridDim.x) {
         const Tile q = decode_tile(t, tiles_h, tiles_w, RT);
         __syncthreads();
         stage_tile<IH, IW, false>(xl, x, nullptr, q.img, q.h0 - d.pt, q.w0 - d.pl, H, W, d.cin, kc * 32);
-        if (dymul) stage_tile<RT, TW, true>(gl, dy, dymul, q.img, q.h0, q.w0, H, W, d.ngemm, 0);
-        else stage_tile<RT, TW, false>(gl, dy, dymul, q.img, q.h0, q.w0, H, W, d.ngemm, 0);
-        __syncthreads();
+#pragma unroll
+        for (int nc = 0; nc < NCH; ++nc) {
+            if (nc > 0) __syncthreads();             // every wave is done with the previous chunk
+            if (dymul) stage_tile<RT, TW, true>(gl, dy, dymul, q.img, q.h0, q.w0, H, W, d.ngemm, nc * 32);
+            else stage_tile<RT, TW, false>(gl, dy, dymul, q.img, q.h0, q.w0, H, W, d.ngemm, nc * 32);
+            __syncthreads();
 #pragma unroll 4
-        for (int pp = 0; pp < RT * 4; ++pp) {
-            const int px = pp * 2 + h;               // within this wave's RT/4 rows
-            const int row = wv * (RT / 4) + (px >> 5), col = px & 31;
-            const float bv = gl[(row * TW + col) * 32 + r];
-            bsum += bv;
+            for (int pp = 0; pp < RT * 4; ++pp) {
+                const int px = pp * 2 + h;               // within this wave's RT/4 rows
+                const int row = wv * (RT / 4) + (px >> 5), col = px & 31;
+                const float bv = gl[(row * TW + col) * 32 + r];
+                bsum[nc] += bv;
 #pragma unroll
-            for (int a = 0; a < KH; ++a)
+                for (int a = 0; a < KH; ++a)
 #pragma unroll
-                for (int b = 0; b < KW; ++b) {
-                    const float av = xl[((row + a) * IW + (col + b)) * 32 + r];
-                    if constexpr (TAPS == 16) mfma_acc(acc[a * KW + b], av, bv);
-                    else acc[a * KW + b] = mfma32(av, bv, acc[a * KW + b]);
-                }
+                    for (int b = 0; b < KW; ++b) {
+                        const float av = xl[((row + a) * IW + (col + b)) * 32 + r];
+                        if constexpr (TAPS == 16) mfma_acc(acc[(a * KW + b) * NCH + nc], av, bv);
+                        else acc[(a * KW + b) * NCH + nc] = mfma32(av, bv, acc[(a * KW + b) * NCH + nc]);
+                    }
+            }
         }
     }
     // slabs: partial[((split*tiles_total + tile)*16 + reg)*64 + lane], split = (wg, wave),
-    // tile = tap*kchunks + kc (one 32-column tile)
+    // tile = (tap*kchunks + kc)*NCH + nc (32 x 32 each)
     const long split = (long)bx * 4 + wv;
-    const long tiles_total = (long)TAPS * kchunks;
+    const long tiles_total = (long)TAPS * kchunks * NCH;
 #pragma unroll
-    for (int t = 0; t < TAPS; ++t) {
-        float* dst = partial + ((split * tiles_total + (long)t * kchunks + kc) * 16) * 64 + lane;
+    for (int t = 0; t < TAPS; ++t)
 #pragma unroll
-        for (int reg = 0; reg < 16; ++reg) dst[reg * 64] = acc[t][reg];
+        for (int nc = 0; nc < NCH; ++nc) {
+            float* dst = partial + ((split * tiles_total + ((long)t * kchunks + kc) * NCH + nc) * 16) * 64 + lane;
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) dst[reg * 64] = acc[t * NCH + nc][reg];
+        }
+    if (bpartial && kc == 0) {
+#pragma unroll
+        for (int nc = 0; nc < NCH; ++nc) bpartial[(split * NCH + nc) * 64 + lane] = bsum[nc];
     }
-    if (bpartial && kc == 0) bpartial[split * 64 + lane] = bsum;
 }
 
 int tile_grid(long ntiles) {
@@ -230,9 +243,12 @@ int mgx_tconv_launch(const mgx_conv_desc& d, const float* x, const float* xmul, 
     return mgx_tconv3_launch(d, x, xmul, w, bias, y, dact, st);   // tconv3.hip
 }
 
-// weight gradient: same applicability on the FORWARD descriptor, output channels must be 32
+// weight gradient: same applicability on the FORWARD descriptor; 32 output channels, or the 1x1
+// convolution 32 -> 128
 bool mgx_twgrad_applicable(const mgx_conv_desc& d) {
-    return mgx_tconv_applicable(d) && d.kh >= 2 && d.sh == 1 && d.sw == 1 && d.ngemm == 32 && d.flip == 0;
+    if (!mgx_tconv_applicable(d) || d.sh != 1 || d.sw != 1 || d.dkh != 1 || d.dkw != 1 || d.flip != 0) return false;
+    if (d.kh == 1) return d.cin == 32 && d.ngemm == 128;        // 1x1, four output chunks
+    return d.ngemm == 32;
 }
 
 bool mgx_pointwise2_applicable(const mgx_conv_desc& d);   // conv_gemm.hip
@@ -270,7 +286,13 @@ int mgx_twgrad_launch(const mgx_conv_desc& d, const float* x, const float* dy, c
 #define MGX_TWGRAD(KK, RR)                                                                                         \
     hipLaunchKernelGGL((twgrad_kernel<KK, KK, RR>), grid, block, (twgrad_lds_bytes<KK, KK, RR>()), st, d, x, dy,   \
                        dymul, partial, bpartial, ntiles, tiles_h, tiles_w)
-    if (d.kh == 4) MGX_TWGRAD(4, 4);
+    if (d.kh == 1 && rt == 8)
+        hipLaunchKernelGGL((twgrad_kernel<1, 1, 8, 4>), grid, block, (twgrad_lds_bytes<1, 1, 8>()), st, d, x, dy, dymul,
+                           partial, bpartial, ntiles, tiles_h, tiles_w);
+    else if (d.kh == 1)
+        hipLaunchKernelGGL((twgrad_kernel<1, 1, 4, 4>), grid, block, (twgrad_lds_bytes<1, 1, 4>()), st, d, x, dy, dymul,
+                           partial, bpartial, ntiles, tiles_h, tiles_w);
+    else if (d.kh == 4) MGX_TWGRAD(4, 4);
     else if (d.kh == 3 && rt == 8) MGX_TWGRAD(3, 8);
     else if (d.kh == 3) MGX_TWGRAD(3, 4);
     else if (rt == 8) MGX_TWGRAD(2, 8);

@@ -66,6 +66,8 @@ CONV_CASES = [
     (32, 132, 32, 32, (2, 2), (2, 2), "valid", 2),    # the same over two tile rows and three tile columns
     (6, 41, 2, 128, (1, 1), (1, 1), "same", 2),
     (6, 41, 32, 128, (1, 1), (1, 1), "same", 2),
+    (16, 70, 32, 128, (1, 1), (1, 1), "same", 3),     # tile kernels: weight gradient over four output chunks
+    (4, 45, 32, 128, (1, 1), (1, 1), "same", 2),      # the same on 4-row tiles
     (1, 100, 2, 128, (1, 2), (1, 2), "valid", 5),     # generator stage-0 input conv
     (8, 60, 2, 128, (2, 2), (2, 2), "valid", 2),      # generator grow-block input conv
 ]
