@@ -53,24 +53,30 @@ __device__ __forceinline__ Tile decode_tile(long t, int tiles_h, int tiles_w, in
 // the row is a scalar offset, rows outside the image use an empty buffer.  The columns beyond 32
 // are one more load of the first (IW-32)*IH*8 threads.  No per-load address arithmetic: vector-ALU
 // instructions take issue time from the MFMAs of the co-resident workgroup.
+// `gather` (1x1 windows only): the staged image is the (a, b) phase of a 32-channel image twice as
+// large, a = gather >> 1 & 1, b = gather & 1 with bit 2 set: position (i, j) reads (2i + a, 2j + b).
 template <int IH, int IW, bool MUL>
 __device__ __forceinline__ void stage_tile(float* lds, const float* __restrict__ x, const float* __restrict__ xmul,
-                                           long img, int hbase, int wbase, int H, int W, int ctot, int c0) {
+                                           long img, int hbase, int wbase, int H, int W, int ctot, int c0,
+                                           int gather = 0) {
     constexpr int ROWB = 4;                               // rows in flight (bounds the staging registers)
     constexpr int XC = IW - 32;                           // columns beyond the 32 of the main pass
     constexpr int NRES = XC * IH * 8;
     const int tid = threadIdx.x, c4 = tid & 7, col = tid >> 3;
-    const long origin = ((img * H + hbase) * (long)W + wbase) * ctot + c0;
+    const int cstr = gather ? 64 : ctot;                  // floats between columns / between rows of the window
+    const int rstr = gather ? 4 * W * 32 : W * ctot;
+    const long origin = gather ? ((img * 2 * H + 2 * hbase + ((gather >> 1) & 1)) * (2L * W) + 2 * wbase + (gather & 1)) * 32
+                               : ((img * H + hbase) * (long)W + wbase) * ctot + c0;
     // the scalar row offset takes part in the range check: the range spans the whole window
-    const unsigned range = (unsigned)((IH * W + IW) * ctot * 4);
+    const unsigned range = (unsigned)((IH * rstr + IW * cstr) * 4);
     const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)(x + origin), 0, range, 0x00020000);
     const __amdgpu_buffer_rsrc_t rz = __builtin_amdgcn_make_buffer_rsrc((void*)(x + origin), 0, 0, 0x00020000);
     const __amdgpu_buffer_rsrc_t mx =
         __builtin_amdgcn_make_buffer_rsrc((void*)((MUL ? xmul : x) + origin), 0, range, 0x00020000);
     const __amdgpu_buffer_rsrc_t mz =
         __builtin_amdgcn_make_buffer_rsrc((void*)((MUL ? xmul : x) + origin), 0, 0, 0x00020000);
-    const unsigned vmain = (unsigned)(col + wbase) < (unsigned)W ? (unsigned)((col * ctot + c4 * 4) * 4) : 0x80000000u;
-    const int row_bytes = W * ctot * 4;
+    const unsigned vmain = (unsigned)(col + wbase) < (unsigned)W ? (unsigned)((col * cstr + c4 * 4) * 4) : 0x80000000u;
+    const int row_bytes = rstr * 4;
     float* dst = lds + col * 32 + c4 * 4;
 #pragma unroll
     for (int i0 = 0; i0 < IH; i0 += ROWB) {
@@ -94,7 +100,7 @@ __device__ __forceinline__ void stage_tile(float* lds, const float* __restrict__
         const int rrow = tid / (XC * 8), rem = tid - rrow * (XC * 8);
         const int rcol = 32 + (rem >> 3), rq = rem & 7;
         const bool ok = tid < NRES && (unsigned)(hbase + rrow) < (unsigned)H && (unsigned)(rcol + wbase) < (unsigned)W;
-        const unsigned vres = ok ? (unsigned)(((rrow * W + rcol) * ctot + rq * 4) * 4) : 0x80000000u;
+        const unsigned vres = ok ? (unsigned)((rrow * rstr + rcol * cstr + rq * 4) * 4) : 0x80000000u;
         f32x4 v = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, vres, 0, 0));
         if (MUL) v *= __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(mx, vres, 0, 0));
         if (tid < NRES) *(f32x4*)(lds + (rrow * IW + rcol) * 32 + rq * 4) = v;
@@ -114,19 +120,21 @@ __global__ __launch_bounds__(256, KH * KW == 16 ? 1 : 2) void twgrad_kernel(mgx_
                                                         const float* __restrict__ dy,
                                                         const float* __restrict__ dymul, float* __restrict__ partial,
                                                         float* __restrict__ bpartial, long ntiles, int tiles_h,
-                                                        int tiles_w) {
+                                                        int tiles_w, int gather) {
+    // gather (1x1 kernels): the weight gradient of a 2x2 stride-2 convolution 32 -> 32; input chunk
+    // kc is the (kc >> 1, kc & 1) phase of the 32-channel input, twice the size of the output
     extern __shared__ __attribute__((aligned(16))) float lds[];
     constexpr int IH = RT + KH - 1, IW = TW + KW - 1, TAPS = KH * KW;
     float* xl = lds;                    // [IH*IW][32]
     float* gl = lds + IH * IW * 32;     // [RT*TW][32]
     const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
     const int r = lane & 31, h = lane >> 5;
-    const int H = d.hin, W = d.win;
+    const int H = d.hout, W = d.wout;       // tiles are laid over the output image (== input unless gathered)
     // the input chunks of a tile share its output-gradient tile: keep them on one XCD (workgroups go
     // to the XCDs round-robin by linear id); slabs are addressed by (chunk, split), sums unchanged
     unsigned bx = blockIdx.x;
     int kc = blockIdx.y;
-    const int kchunks = d.cin / 32;
+    const int kchunks = gridDim.y;
     if (gridDim.y > 1 && (gridDim.x & 7) == 0) {
         const unsigned lin = blockIdx.x + blockIdx.y * gridDim.x, q = lin >> 3;
         kc = (int)(q % gridDim.y);
@@ -145,7 +153,8 @@ __global__ __launch_bounds__(256, KH * KW == 16 ? 1 : 2) void twgrad_kernel(mgx_
     for (long t = bx; t < ntiles; t += gridDim.x) {
         const Tile q = decode_tile(t, tiles_h, tiles_w, RT);
         __syncthreads();
-        stage_tile<IH, IW, false>(xl, x, nullptr, q.img, q.h0 - d.pt, q.w0 - d.pl, H, W, d.cin, kc * 32);
+        if (KH == 1 && gather) stage_tile<IH, IW, false>(xl, x, nullptr, q.img, q.h0, q.w0, H, W, 32, 0, 4 | kc);
+        else stage_tile<IH, IW, false>(xl, x, nullptr, q.img, q.h0 - d.pt, q.w0 - d.pl, H, W, d.cin, kc * 32);
 #pragma unroll
         for (int nc = 0; nc < NCH; ++nc) {
             if (nc > 0) __syncthreads();             // every wave is done with the previous chunk
@@ -245,10 +254,19 @@ int mgx_tconv_launch(const mgx_conv_desc& d, const float* x, const float* xmul, 
 
 // weight gradient: same applicability on the FORWARD descriptor; 32 output channels, or the 1x1
 // convolution 32 -> 128
+static bool twgrad_strided2_applicable(const mgx_conv_desc& d);
+
 bool mgx_twgrad_applicable(const mgx_conv_desc& d) {
+    if (twgrad_strided2_applicable(d)) return true;
     if (!mgx_tconv_applicable(d) || d.sh != 1 || d.sw != 1 || d.dkh != 1 || d.dkw != 1 || d.flip != 0) return false;
     if (d.kh == 1) return d.cin == 32 && d.ngemm == 128;        // 1x1, four output chunks
     return d.ngemm == 32;
+}
+
+// the 2x2 stride-2 'valid' convolution 32 -> 32: as a 1x1 weight gradient over the four phases
+static bool twgrad_strided2_applicable(const mgx_conv_desc& d) {
+    return strided2_applicable(d) && d.sh == 2 && d.hout % 4 == 0 &&
+           (long)4 * (TH + 1) * d.win * 32 * 4 < (1L << 31);
 }
 
 bool mgx_pointwise2_applicable(const mgx_conv_desc& d);   // conv_gemm.hip
@@ -272,26 +290,33 @@ extern "C" int mgx_conv_route(const mgx_conv_desc* d, int wgrad) {
 }
 
 long mgx_twgrad_splits(const mgx_conv_desc& d) {
-    const int rt = (d.hin % TH || d.kh == 4) ? 4 : TH;
-    const int tiles_h = d.hin / rt, tiles_w = (d.win + TW - 1) / TW;
+    const int rt = (d.hout % TH || d.kh == 4) ? 4 : TH;
+    const int tiles_h = d.hout / rt, tiles_w = (d.wout + TW - 1) / TW;
     return (long)tile_grid((long)d.nimg * tiles_h * tiles_w) * 4;
 }
 
 int mgx_twgrad_launch(const mgx_conv_desc& d, const float* x, const float* dy, const float* dymul, float* partial,
                       float* bpartial, hipStream_t st) {
-    const int rt = (d.hin % TH || d.kh == 4) ? 4 : TH;
-    const int tiles_h = d.hin / rt, tiles_w = (d.win + TW - 1) / TW;
+    const int rt = (d.hout % TH || d.kh == 4) ? 4 : TH;
+    const int tiles_h = d.hout / rt, tiles_w = (d.wout + TW - 1) / TW;
     const long ntiles = (long)d.nimg * tiles_h * tiles_w;
-    dim3 grid(tile_grid(ntiles), d.cin / 32), block(256);
+    const bool s2 = d.sh == 2;
+    dim3 grid(tile_grid(ntiles), s2 ? 4 : d.cin / 32), block(256);
 #define MGX_TWGRAD(KK, RR)                                                                                         \
     hipLaunchKernelGGL((twgrad_kernel<KK, KK, RR>), grid, block, (twgrad_lds_bytes<KK, KK, RR>()), st, d, x, dy,   \
-                       dymul, partial, bpartial, ntiles, tiles_h, tiles_w)
-    if (d.kh == 1 && rt == 8)
+                       dymul, partial, bpartial, ntiles, tiles_h, tiles_w, 0)
+    if (s2 && rt == 8)
+        hipLaunchKernelGGL((twgrad_kernel<1, 1, 8, 1>), grid, block, (twgrad_lds_bytes<1, 1, 8>()), st, d, x, dy, dymul,
+                           partial, bpartial, ntiles, tiles_h, tiles_w, 1);
+    else if (s2)
+        hipLaunchKernelGGL((twgrad_kernel<1, 1, 4, 1>), grid, block, (twgrad_lds_bytes<1, 1, 4>()), st, d, x, dy, dymul,
+                           partial, bpartial, ntiles, tiles_h, tiles_w, 1);
+    else if (d.kh == 1 && rt == 8)
         hipLaunchKernelGGL((twgrad_kernel<1, 1, 8, 4>), grid, block, (twgrad_lds_bytes<1, 1, 8>()), st, d, x, dy, dymul,
-                           partial, bpartial, ntiles, tiles_h, tiles_w);
+                           partial, bpartial, ntiles, tiles_h, tiles_w, 0);
     else if (d.kh == 1)
         hipLaunchKernelGGL((twgrad_kernel<1, 1, 4, 4>), grid, block, (twgrad_lds_bytes<1, 1, 4>()), st, d, x, dy, dymul,
-                           partial, bpartial, ntiles, tiles_h, tiles_w);
+                           partial, bpartial, ntiles, tiles_h, tiles_w, 0);
     else if (d.kh == 4) MGX_TWGRAD(4, 4);
     else if (d.kh == 3 && rt == 8) MGX_TWGRAD(3, 8);
     else if (d.kh == 3) MGX_TWGRAD(3, 4);
