@@ -257,6 +257,59 @@ int mgx_adam_multi_devlr(float* const* p, const int64_t* n, const int64_t* off, 
                          const int32_t* blk_tensor, const int64_t* blk_start, int64_t nblocks,
                          const float* lr_t, float beta2, float eps, void* stream);
 
+/* ------------------------------------------------------------------------------------------
+ * bf16 path of the discriminator's grow blocks (add_discriminator_block, models.py:256-281, and its
+ * tf.GradientTape gradients, models.py:118, 144): activations with 32 / 128 channels are stored as
+ * NHWC bfloat16, every contraction runs on v_mfma_f32_32x32x16_bf16 with float32 accumulation, weights,
+ * biases and all gradients of variables stay float32 (master copies; the kernels round the weights to
+ * bf16 as they stage them).  2-channel tensors (audio, its gradient) stay float32.
+ * Pointers typed void* are bf16 device tensors.
+ * ------------------------------------------------------------------------------------------ */
+
+/* 1 if mgx_conv_gemm_bf16 serves the descriptor: stride-1 'same' 3x3 / 2x2 / 1x1 convolutions (forward or
+ * data-gradient tap order) between 32 and 32 or 128 channels, the 2x2 stride-2 'valid' convolution
+ * 32 -> 32 and its depth-to-space data-gradient. */
+int mgx_conv_bf16_supported(const mgx_conv_desc* d);
+
+/* The contraction of mgx_conv_gemm_f32 on bf16 activations (Conv2D + SoftRectifier of models.py:259-281):
+ * x, y bf16; w, bias float32.  With d->act_alpha > 0 the epilogue is tanh(v)+v/alpha and dact (may be
+ * NULL) receives the derivative as bf16.  ymul (may be NULL; then no bias / activation): the result is
+ * multiplied element-wise by this bf16 tensor of the output's shape before it is stored: the
+ * data-gradient of a convolution whose input came out of an activation, dX = (W^T dY) (.) f'.
+ * d->accumulate must be 0. */
+int mgx_conv_gemm_bf16(const mgx_conv_desc* d, const void* x, const float* w, const float* bias, void* y,
+                       void* dact, const void* ymul, void* stream);
+
+/* Weight / bias gradient for a forward descriptor mgx_conv_bf16_supported accepts: x the layer input,
+ * g the gradient with respect to the pre-activation (both bf16); dw (Keras layout through the
+ * descriptor's strides) and dbias (may be NULL) are float32 and are ADDED to.  Fixed-order two-stage
+ * reduction through `workspace` (mgx_conv_wgrad_bf16_workspace bytes). */
+int64_t mgx_conv_wgrad_bf16_workspace(const mgx_conv_desc* d);
+int mgx_conv_wgrad_bf16(const mgx_conv_desc* d, const void* x, const void* g, float* dw, float* dbias,
+                        void* workspace, int64_t workspace_bytes, void* stream);
+
+/* From-audio 1x1 convolution (models.py:256): x float32 (npos, 2) -> y bf16 (npos, 128) with kernel w
+ * (2,128) and bias (128) float32, optional tanh(v)+v/alpha epilogue (act_alpha > 0) and derivative
+ * store (dact, bf16, may be NULL).  Its weight gradient (dw (2,128), db (128) ADDED to; g = gradient
+ * with respect to the pre-activation, bf16) and its data-gradient dx (npos, 2) float32 (+)= g W^T. */
+int mgx_pointwise2_bf16_fwd(const float* x, const float* w, const float* bias, void* y, void* dact, int64_t npos,
+                            float act_alpha, void* stream);
+int64_t mgx_pointwise2_bf16_wgrad_workspace(int64_t npos);
+int mgx_pointwise2_bf16_wgrad(const float* x, const void* g, float* dw, float* db, void* workspace,
+                              int64_t workspace_bytes, int64_t npos, void* stream);
+int mgx_pointwise_to2_bf16(const void* g, const float* w, float* dx, int64_t npos, int accumulate, void* stream);
+
+/* WeightedSum (models.py:30-35) on bf16 tensors of n elements (n a multiple of 8); dalpha += sum dy (b - a)
+ * (float32, workspace of mgx_reduce_workspace() bytes); da, db, dalpha may be NULL. */
+int mgx_weighted_sum_bf16_fwd(const void* a, const void* b, const float* alpha, void* y, int64_t n, void* stream);
+int mgx_weighted_sum_bf16_bwd(const void* dy, const void* a, const void* b, const float* alpha, void* da, void* db,
+                              float* dalpha, void* workspace, int64_t workspace_bytes, int64_t n, void* stream);
+
+/* Casts at the boundary between the bf16 grow blocks and the float32 base block (no counterpart in the
+ * reference, which runs float32 throughout). */
+int mgx_cast_f32_to_bf16(const float* x, void* y, int64_t n, void* stream);
+int mgx_cast_bf16_to_f32(const void* x, float* y, int64_t n, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

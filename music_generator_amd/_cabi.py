@@ -95,6 +95,18 @@ PROTOTYPES = {
     "mgx_adam_multi_m": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I64, _F, _F, _F, _F, _P]),
     "mgx_softmax_xent": (_I, [_P, _P, _P, _P, _P, _I64, _I, _P]),
     "mgx_adam_multi_devlr": (_I, [_P, _P, _P, _P, _P, _P, _P, _I64, _P, _F, _F, _P]),
+    "mgx_conv_bf16_supported": (_I, [_DESC]),
+    "mgx_conv_gemm_bf16": (_I, [_DESC, _P, _P, _P, _P, _P, _P, _P]),
+    "mgx_conv_wgrad_bf16_workspace": (_I64, [_DESC]),
+    "mgx_conv_wgrad_bf16": (_I, [_DESC, _P, _P, _P, _P, _P, _I64, _P]),
+    "mgx_pointwise2_bf16_fwd": (_I, [_P, _P, _P, _P, _P, _I64, _F, _P]),
+    "mgx_pointwise2_bf16_wgrad_workspace": (_I64, [_I64]),
+    "mgx_pointwise2_bf16_wgrad": (_I, [_P, _P, _P, _P, _P, _I64, _I64, _P]),
+    "mgx_pointwise_to2_bf16": (_I, [_P, _P, _P, _I64, _I, _P]),
+    "mgx_weighted_sum_bf16_fwd": (_I, [_P, _P, _P, _P, _I64, _P]),
+    "mgx_weighted_sum_bf16_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I64, _I64, _P]),
+    "mgx_cast_f32_to_bf16": (_I, [_P, _P, _I64, _P]),
+    "mgx_cast_bf16_to_f32": (_I, [_P, _P, _I64, _P]),
 }
 
 _lib = None

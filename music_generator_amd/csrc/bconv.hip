@@ -1,0 +1,298 @@
+// bf16 convolutions of the discriminator's grow blocks (trainer/models.py:256-281): stride-1 'same'
+// 3x3 / 2x2 / 1x1 convolutions between 32- and 128-channel NHWC bf16 tensors, the 2x2 stride-2 'valid'
+// convolution, and the data-gradient of each, on v_mfma_f32_32x32x16_bf16 with float32 accumulation.
+//
+// One workgroup of 8 waves per CU walks tiles of 8 rows x 64 columns; wave w owns row w as two
+// accumulator tiles D[output channel][position] (32 x 32 each): the output channels are the MFMA rows,
+// so that after one exchange between the lane halves every lane holds 16 consecutive channels of one
+// position and stores them as 32 contiguous bytes.
+// LDS holds
+//   * the whole weight tensor, converted once per workgroup from the float32 master copy (Keras
+//     layout, read through the descriptor's strides) to bf16 in MFMA-fragment order
+//     [chunk][tap][k-step][lane][8], so the A operand is one lane-linear ds_read_b128;
+//   * two input tiles with halo ((8+kh-1) x (64+kw-1) positions x 32 channels = 64 B a position, the
+//     four 16-byte quads of a position XOR-swizzled with bits 2-3 of the position index, which makes
+//     the B-operand ds_read_b128 of 32 consecutive positions conflict-free): while the MFMAs run
+//     on one, the next tile's global loads are in flight into registers and are written to the other
+//     buffer afterwards; one barrier per step.
+// 128 input (output) channels run as 4 steps per tile over 32-channel slices with the accumulator
+// (the staged tile) kept.  Positions outside the image read as zeros through out-of-range buffer
+// offsets; columns past the row end are dropped by the store's range check.
+// Epilogues: bias + tanh(x)+x/alpha (+ optional store of the derivative for the backward pass);
+// multiply by a bf16 tensor of the output's shape (the data-gradient of a convolution whose input came
+// out of an activation: dY (.) f'); or plain.
+#include "bf16.h"
+#include "../../include/mgx.h"
+
+namespace {
+
+constexpr int TH = 8, TW = 64;
+
+template <int KH, int KW>
+constexpr int npix() { return (TH + KH - 1) * (TW + KW - 1); }
+
+// byte offset of quad q (8 channels) of tile position p
+__device__ __forceinline__ int xoff(int p, int q) { return p * 64 + ((q ^ ((p >> 2) & 3)) << 4); }
+
+template <int KH, int KW, int EPI>
+__global__ __launch_bounds__(512, 2) void bconv_kernel(mgx_conv_desc d, const bf16_t* __restrict__ x,
+                                                       const float* __restrict__ w, const float* __restrict__ bias,
+                                                       bf16_t* __restrict__ y, bf16_t* __restrict__ dact,
+                                                       const bf16_t* __restrict__ ymul, long ntiles, int tiles_h,
+                                                       int tiles_w, int gin_w, int scat) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    constexpr int IH = TH + KH - 1, IW = TW + KW - 1, TAPS = KH * KW, NPIX = IH * IW;
+    constexpr int SITER = (NPIX * 4 + 511) / 512;            // 16-byte staging loads per thread
+    const int tid = threadIdx.x;
+    const int lane = tid & 63;
+    const int r = lane & 31, h = lane >> 5;
+    const int wvs = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int H = d.hin, W = d.win;
+    const int kchunks = d.cin / 32, nchunks = d.ngemm / 32;   // one of them is 1
+    const int S = kchunks * nchunks;
+    const int K = d.cin, N = d.ngemm;
+    unsigned char* wl = lds;                                   // [nchunk][tap][K/16][64 lanes][16 B]
+    unsigned char* xt = lds + TAPS * K * N * 2;                // [2][NPIX][64 B]
+
+    // ---- weights: float32 global -> bf16 fragments in LDS (once per workgroup) ----
+    {
+        const int total = TAPS * K * N;
+        const bool n_fast = d.wsn == 1;
+        for (int i = tid; i < total; i += 512) {
+            int tap, k, n;
+            if (n_fast) { n = i % N; const int t2 = i / N; k = t2 % K; tap = t2 / K; }
+            else { k = i % K; const int t2 = i / K; n = t2 % N; tap = t2 / N; }
+            const int wt = d.flip ? (TAPS - 1 - tap) : tap;
+            const float v = w[(long)wt * d.wtap + (long)k * d.wsk + (long)n * d.wsn];
+            const int nc = n >> 5, f = (nc * TAPS + tap) * (K >> 4) + (k >> 4);
+            const int ln = ((k >> 3) & 1) * 32 + (n & 31);
+            *(bf16_t*)(wl + ((f * 64 + ln) * 8 + (k & 7)) * 2) = (bf16_t)v;
+        }
+    }
+
+    // ---- input tile staging: thread t moves 16-byte piece #(t + 512 i) = (position, quad) ----
+    auto tile_of = [&](long t, long& img, int& h0, int& w0) {
+        const unsigned per_img = (unsigned)(tiles_h * tiles_w);
+        const unsigned tu = (unsigned)t;
+        const unsigned im = tu / per_img;
+        const unsigned rem = tu - im * per_img;
+        const unsigned th = rem / (unsigned)tiles_w;
+        img = im;
+        h0 = (int)th * TH;
+        w0 = (int)(rem - th * tiles_w) * TW;
+    };
+    const int q4 = tid & 3;
+    const unsigned band_bytes = gin_w > 0 ? (unsigned)(2 * IH) * gin_w * 64u : (unsigned)IH * W * d.cin * 2u;
+    int rel[SITER], tyx[SITER];
+#pragma unroll
+    for (int i = 0; i < SITER; ++i) {
+        const int px = (tid >> 2) + 128 * i;
+        const int ty = px / IW, tx = px - ty * IW;
+        rel[i] = gin_w > 0 ? ((ty * 2 * gin_w + 2 * tx) * 32 + q4 * 8) * 2 : ((ty * W + tx) * d.cin + q4 * 8) * 2;
+        tyx[i] = px < NPIX ? ((ty << 16) | tx) : (0x7000 << 16);
+    }
+    u32x4 sv[SITER];
+    auto stage_load = [&](long t, int kc) {
+        long img; int h0, w0;
+        tile_of(t, img, h0, w0);
+        const int hb = h0 - d.pt, wb = w0 - d.pl;
+        const int base = gin_w > 0 ? ((2 * w0 + (kc & 1)) * 32 + (kc >> 1) * gin_w * 32) * 2 : (wb * d.cin + kc * 32) * 2;
+        const long band = gin_w > 0 ? ((img * 2 * H + 2 * h0) * (long)gin_w) * 32 : ((img * H + hb) * (long)W) * d.cin;
+        const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)(x + band), 0, band_bytes, 0x00020000);
+#pragma unroll
+        for (int i = 0; i < SITER; ++i) {
+            const unsigned hi = (unsigned)((tyx[i] >> 16) + hb), wi = (unsigned)((tyx[i] & 0xffff) + wb);
+            const unsigned off = (hi < (unsigned)H && wi < (unsigned)W) ? (unsigned)(base + rel[i]) : 0xfffffff0u;
+            sv[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, off, 0, 0));
+        }
+    };
+    auto stage_write = [&](unsigned char* buf) {
+#pragma unroll
+        for (int i = 0; i < SITER; ++i) {
+            const int px = (tid >> 2) + 128 * i;
+            if (128 * (i + 1) <= NPIX || px < NPIX) *(u32x4*)(buf + xoff(px, q4)) = sv[i];
+        }
+    };
+
+    long t = blockIdx.x;
+    int oc = 0;
+    if (t < ntiles) {
+        stage_load(t, 0);
+        stage_write(xt);
+    }
+    __syncthreads();
+    const float inv_alpha = d.act_alpha > 0.f ? 1.0f / d.act_alpha : 0.f;
+    const float k1 = 1.0f + inv_alpha;
+    int cur = 0;
+    f32x16 acc0, acc1;
+#pragma unroll
+    for (int i = 0; i < 16; ++i) { acc0[i] = 0.f; acc1[i] = 0.f; }
+
+    // ---- epilogue of the wave's row of tile t_, output channel chunk nc_ ----
+    auto epilogue = [&](f32x16& a0, f32x16& a1, long t_, int nc_) {
+        long img; int h0, w0;
+        tile_of(t_, img, h0, w0);
+        const int row = h0 + wvs;
+        const long rowoff = scat ? ((img * 2 * H + 2 * row + (nc_ >> 1)) * (2L * W)) * 32
+                                 : ((img * H + row) * (long)W) * N;
+        const unsigned row_bytes = row < H ? (scat ? 2u * W * 64u : (unsigned)W * N * 2u) : 0u;
+        const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc((void*)(y + rowoff), 0, row_bytes, 0x00020000);
+        const int pstride = scat ? 128 : N * 2;                   // bytes between consecutive columns
+        const int coff = scat ? (nc_ & 1) * 64 + 32 * h : (nc_ * 32 + 16 * h) * 2;
+        float bv[16];
+        if (EPI == 1) {
+#pragma unroll
+            for (int i = 0; i < 16; ++i) bv[i] = d.nbias > 0 ? bias[nc_ * 32 + 16 * h + i] : 0.f;
+        }
+        mfma_result_wait();
+#pragma unroll
+        for (int nt = 0; nt < 2; ++nt) {
+            f32x16& a = nt ? a1 : a0;
+            acc_rows_contiguous(a);
+            const unsigned voff = (unsigned)((w0 + nt * 32 + r) * pstride + coff);
+            unsigned o[8], dd[8];
+            if (EPI == 1) {
+                if (d.act_alpha > 0.f) {
+#pragma unroll
+                    for (int i = 0; i < 16; i += 2) {
+                        float y0, y1, d0, d1;
+                        act_bf16(a[i] + bv[i], inv_alpha, k1, y0, d0);
+                        act_bf16(a[i + 1] + bv[i + 1], inv_alpha, k1, y1, d1);
+                        o[i >> 1] = bf_pack(y0, y1);
+                        dd[i >> 1] = bf_pack(d0, d1);
+                    }
+                } else {
+#pragma unroll
+                    for (int i = 0; i < 16; i += 2) o[i >> 1] = bf_pack(a[i] + bv[i], a[i + 1] + bv[i + 1]);
+                }
+            } else if (EPI == 2) {
+                const __amdgpu_buffer_rsrc_t rm =
+                    __builtin_amdgcn_make_buffer_rsrc((void*)(ymul + rowoff), 0, row_bytes, 0x00020000);
+                const u32x4 m0 = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rm, voff, 0, 0));
+                const u32x4 m1 = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rm, voff + 16, 0, 0));
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    o[i] = bf_pack(a[2 * i] * bf_lo(m0[i]), a[2 * i + 1] * bf_hi(m0[i]));
+                    o[4 + i] = bf_pack(a[8 + 2 * i] * bf_lo(m1[i]), a[8 + 2 * i + 1] * bf_hi(m1[i]));
+                }
+            } else {
+#pragma unroll
+                for (int i = 0; i < 16; i += 2) o[i >> 1] = bf_pack(a[i], a[i + 1]);
+            }
+            u32x4 s0 = {o[0], o[1], o[2], o[3]}, s1 = {o[4], o[5], o[6], o[7]};
+            __builtin_amdgcn_raw_buffer_store_b128(s0, ry, voff, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b128(s1, ry, voff + 16, 0, 0);
+            if (EPI == 1 && dact != nullptr && d.act_alpha > 0.f) {
+                const __amdgpu_buffer_rsrc_t rd =
+                    __builtin_amdgcn_make_buffer_rsrc((void*)(dact + rowoff), 0, row_bytes, 0x00020000);
+                u32x4 e0 = {dd[0], dd[1], dd[2], dd[3]}, e1 = {dd[4], dd[5], dd[6], dd[7]};
+                __builtin_amdgcn_raw_buffer_store_b128(e0, rd, voff, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b128(e1, rd, voff + 16, 0, 0);
+            }
+        }
+    };
+
+    while (t < ntiles) {
+        int ocn = oc + 1;
+        long tn = t;
+        if (ocn == S) { ocn = 0; tn = t + gridDim.x; }
+        const bool has_next = tn < ntiles;
+        const bool need_x = has_next && (kchunks > 1 || ocn == 0);
+        if (need_x) stage_load(tn, kchunks > 1 ? ocn : 0);
+        const unsigned char* xb = xt + cur * (NPIX * 64);
+        const int kc = kchunks > 1 ? oc : 0, nc = nchunks > 1 ? oc : 0;
+        const unsigned char* wb = wl + ((nc * TAPS * (K >> 4) + kc * 2) * 64 + lane) * 16;
+#pragma unroll
+        for (int tap = 0; tap < TAPS; ++tap) {
+            const int ta = tap / KW, tb = tap - ta * KW;
+            const int p0 = (wvs + ta) * IW + tb + r;
+#pragma unroll
+            for (int ks = 0; ks < 2; ++ks) {
+                const u32x4 a = *(const u32x4*)(wb + (tap * (K >> 4) + ks) * 1024);
+                const u32x4 b0 = *(const u32x4*)(xb + xoff(p0, 2 * ks + h));
+                const u32x4 b1 = *(const u32x4*)(xb + xoff(p0 + 32, 2 * ks + h));
+                acc0 = mfma_bf16(a, b0, acc0);
+                acc1 = mfma_bf16(a, b1, acc1);
+            }
+        }
+        if (need_x) stage_write(xt + (cur ^ 1) * (NPIX * 64));
+        if (kchunks == 1 || oc == S - 1) {
+            epilogue(acc0, acc1, t, nc);
+#pragma unroll
+            for (int i = 0; i < 16; ++i) { acc0[i] = 0.f; acc1[i] = 0.f; }
+        }
+        __syncthreads();
+        if (need_x) cur ^= 1;
+        t = tn;
+        oc = ocn;
+    }
+}
+
+template <int KH, int KW>
+int launch_b(const mgx_conv_desc& d, const bf16_t* x, const float* w, const float* bias, bf16_t* y, bf16_t* dact,
+             const bf16_t* ymul, hipStream_t st, int gin_w, int scat) {
+    const int tiles_h = (d.hin + TH - 1) / TH, tiles_w = (d.win + TW - 1) / TW;
+    const long ntiles = (long)d.nimg * tiles_h * tiles_w;
+    if (ntiles <= 0 || ntiles >= (1L << 31)) return MGX_ERR_ARG;
+    const unsigned grid = (unsigned)(ntiles < 256 ? ntiles : 256);
+    const int lds = KH * KW * d.cin * d.ngemm * 2 + 2 * npix<KH, KW>() * 64;
+    if (lds > 160 * 1024) return MGX_ERR_ARG;
+    const int epi = ymul != nullptr ? 2 : ((d.nbias > 0 || d.act_alpha > 0.f) ? 1 : 0);
+#define MGX_B(E)                                                                                                     \
+    do {                                                                                                             \
+        if (hipFuncSetAttribute((const void*)bconv_kernel<KH, KW, E>, hipFuncAttributeMaxDynamicSharedMemorySize,    \
+                                lds) != hipSuccess)                                                                  \
+            return MGX_ERR_LAUNCH;                                                                                   \
+        hipLaunchKernelGGL((bconv_kernel<KH, KW, E>), dim3(grid), dim3(512), lds, st, d, x, w, bias, y, dact, ymul,  \
+                           ntiles, tiles_h, tiles_w, gin_w, scat);                                                   \
+    } while (0)
+    if (epi == 2) MGX_B(2);
+    else if (epi == 1) MGX_B(1);
+    else MGX_B(0);
+#undef MGX_B
+    return mgx_launch_status();
+}
+
+}  // namespace
+
+// Which contractions the bf16 tile kernel serves: stride-1 'same' convolutions with kernel 3x3, 2x2 or 1x1
+// (either tap order) and the 2x2 stride-2 'valid' convolution, between 32 and 32 or 128 channels (not 128
+// on both sides), and the depth-to-space data-gradient of the strided one.
+extern "C" int mgx_conv_bf16_supported(const mgx_conv_desc* d) {
+    if (!d) return 0;
+    const bool chans = (d->cin == 32 && (d->ngemm == 32 || d->ngemm == 128)) || (d->cin == 128 && d->ngemm == 32);
+    if (d->sh == 2 && d->sw == 2 && d->kh == 2 && d->kw == 2 && d->dkh == 1 && d->dkw == 1)
+        return d->cin == 32 && d->ngemm == 32 && d->pt == 0 && d->pl == 0 && d->hin == 2 * d->hout &&
+               d->win == 2 * d->wout && d->cout == 32;
+    if (d->dkh == 2 && d->dkw == 2)
+        return d->kh == 1 && d->kw == 1 && d->sh == 1 && d->sw == 1 && d->cin == 32 && d->ngemm == 128 &&
+               d->cout == 32 && d->hin == d->hout && d->win == d->wout;
+    if (d->dkh != 1 || d->dkw != 1 || d->sh != 1 || d->sw != 1 || !chans || d->cout != d->ngemm) return 0;
+    if (d->hin != d->hout || d->win != d->wout) return 0;
+    if (!((d->kh == 3 && d->kw == 3) || (d->kh == 2 && d->kw == 2) || (d->kh == 1 && d->kw == 1))) return 0;
+    if (d->pt < 0 || d->pt >= d->kh || d->pl < 0 || d->pl >= d->kw) return 0;
+    return (d->wsk == 1 || d->wsn == 1) ? 1 : 0;
+}
+
+extern "C" int mgx_conv_gemm_bf16(const mgx_conv_desc* dp, const void* x, const float* w, const float* bias, void* y,
+                                  void* dact, const void* ymul, void* stream) {
+    if (!dp || !x || !w || !y || !mgx_conv_bf16_supported(dp)) return MGX_ERR_ARG;
+    if (dp->accumulate) return MGX_ERR_ARG;
+    if (dp->nbias > 0 && (!bias || dp->nbias != dp->ngemm)) return MGX_ERR_ARG;
+    if (ymul && (dp->nbias > 0 || dp->act_alpha > 0.f)) return MGX_ERR_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    mgx_conv_desc d = *dp;
+    const bf16_t* xb = (const bf16_t*)x;
+    bf16_t* yb = (bf16_t*)y;
+    bf16_t* db = (bf16_t*)dact;
+    const bf16_t* mb = (const bf16_t*)ymul;
+    if (d.sh == 2) {
+        // 2x2 stride-2 convolution = 1x1 convolution over the 128 channels of the gathered window
+        d.hin = dp->hout; d.win = dp->wout; d.cin = 128; d.kh = d.kw = 1; d.sh = d.sw = 1;
+        return launch_b<1, 1>(d, xb, w, bias, yb, db, mb, st, dp->win, 0);
+    }
+    if (d.dkh == 2) return launch_b<1, 1>(d, xb, w, bias, yb, db, mb, st, 0, 1);
+    if (d.kh == 3) return launch_b<3, 3>(d, xb, w, bias, yb, db, mb, st, 0, 0);
+    if (d.kh == 2) return launch_b<2, 2>(d, xb, w, bias, yb, db, mb, st, 0, 0);
+    return launch_b<1, 1>(d, xb, w, bias, yb, db, mb, st, 0, 0);
+}

@@ -1,0 +1,74 @@
+// bf16 storage helpers for the gfx950 kernels that keep activations in bfloat16 and accumulate in
+// float32 (v_mfma_f32_32x32x16_bf16).
+#pragma once
+#include "common.h"
+
+typedef __bf16 bf16_t;
+typedef __bf16 bf16x2 __attribute__((ext_vector_type(2)));
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
+
+// The two bf16 halves of a dword as float32 (exact).
+__device__ __forceinline__ float bf_lo(unsigned u) { return __builtin_bit_cast(float, u << 16); }
+__device__ __forceinline__ float bf_hi(unsigned u) { return __builtin_bit_cast(float, u & 0xffff0000u); }
+
+// Two float32 -> one dword of two bf16, round to nearest even (v_cvt_pk_bf16_f32; NaN stays NaN).
+__device__ __forceinline__ unsigned bf_pack(float lo, float hi) {
+    bf16x2 p;
+    p[0] = (__bf16)lo;
+    p[1] = (__bf16)hi;
+    return __builtin_bit_cast(unsigned, p);
+}
+
+__device__ __forceinline__ float bf_to_f(bf16_t v) { return (float)v; }
+
+// One v_mfma_f32_32x32x16_bf16: D(32x32) = A(32x16) * B(16x32) + C.  Lane l (r = l&31, h = l>>5)
+// supplies A[row r][k = 8h + j] and B[k = 8h + j][col r] in element j of its fragment; element
+// `reg` of the accumulator in lane l is D[row = (reg&3) + 8*(reg>>2) + 4*h][col = r].
+__device__ __forceinline__ f32x16 mfma_bf16(u32x4 a, u32x4 b, f32x16 c) {
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(bf16x8, a), __builtin_bit_cast(bf16x8, b), c,
+                                                   0, 0, 0);
+}
+
+// Wait states between the last MFMA that writes an accumulator and an inline-asm statement that reads it
+// (the compiler pads vector-ALU readers it schedules itself, but nothing inside or in front of asm).
+__device__ __forceinline__ void mfma_result_wait() { asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 3"); }
+
+// After this exchange between lanes l and l^32, lane (r, h) holds rows 16h .. 16h+15 of column r
+// of a 32x32 accumulator tile in a[0..15] (in order).
+__device__ __forceinline__ void acc_rows_contiguous(f32x16& a) {
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            // registers 4g+e (rows 8g+4h+e) and 4(g+2)+e (rows 8(g+2)+4h+e): v_permlane32_swap exchanges the
+            // first operand's lanes 32-63 with the second operand's lanes 0-31.  Inline asm: the builtin of
+            // this toolchain returns the first result twice.  The s_nop covers the wait states between a
+            // vector-ALU write of an operand and the swap (nothing is padded inside an asm statement).
+            float lo = a[4 * g + e], hi = a[4 * (g + 2) + e];
+            asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(lo), "+v"(hi));
+            a[4 * g + e] = lo;
+            a[4 * (g + 2) + e] = hi;
+        }
+    }
+    // lanes < 32 now hold: a[0..3] rows 0-3, a[8..11] rows 4-7, a[4..7] rows 8-11, a[12..15] rows 12-15
+    // lanes >= 32:         a[0..3] rows 16-19, a[8..11] rows 20-23, a[4..7] rows 24-27, a[12..15] rows 28-31
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+        const float t = a[4 + e];
+        a[4 + e] = a[8 + e];
+        a[8 + e] = t;
+    }
+}
+
+// tanh(x) + x/alpha and its derivative 1 - tanh(x)^2 + 1/alpha for bf16 outputs: exp2 and rcp are
+// the hardware approximations, 1 - t*t is taken directly (its cancellation error ~1e-7 is far
+// below the 2^-9 rounding of the stored value).  inv_alpha = 1/alpha, k1 = 1 + 1/alpha.
+__device__ __forceinline__ void act_bf16(float x, float inv_alpha, float k1, float& y, float& dv) {
+    const float e = __builtin_amdgcn_exp2f(2.885390081777927f * x);     // exp(2x); inf / 0 at the ends
+    const float r = __builtin_amdgcn_rcpf(1.0f + e);
+    const float t = __builtin_fmaf(-2.0f, r, 1.0f);
+    y = __builtin_fmaf(x, inv_alpha, t);
+    dv = __builtin_fmaf(-t, t, k1);
+}

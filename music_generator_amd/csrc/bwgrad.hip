@@ -1,0 +1,306 @@
+// Weight / bias gradient of the bf16 discriminator convolutions (tf.GradientTape, trainer/models.py:118)
+// on v_mfma_f32_32x32x16_bf16:
+//     dW[tap][ci][co] += sum_positions X[position + tap][ci] * G[position][co],   dB[co] += sum G
+// with X the layer input and G the gradient with respect to the pre-activation, both NHWC bf16.
+//
+// The contraction index is the position, so both MFMA operands are needed channel-major while the
+// tensors are position-major: tiles are staged to LDS as they lie in memory ([position][32 channels],
+// 64 B a position) and read with ds_read_b64_tr_b16, which hands a lane four consecutive positions of
+// its channel.  A workgroup of 4 waves (one per SIMD, up to 512 registers each) walks tiles of 8 rows x
+// 64 columns; a wave owns two rows and keeps one 32x32 accumulator tile per tap (plus one for the bias,
+// an MFMA against a matrix of ones) for the whole launch.  The gradient fragment of 16 positions is read
+// once and used for every tap.  Two LDS buffers: the next tile's global loads are in flight during the
+// MFMAs of the current one.
+// Tensors with 128 channels on one side are split over workgroups in 32-channel chunks: the four
+// chunks of a tile slot are given to blocks b, b+8, b+16, b+24, which share an XCD under round-robin
+// placement, so the operand they have in common is fetched from HBM once (speed only).
+// At the end the four waves are added in LDS in fixed order, every workgroup leaves one slab in the
+// workspace, and a second kernel adds the slabs in fixed order into dW / dB (bitwise reproducible).
+#include "bf16.h"
+#include "../../include/mgx.h"
+
+namespace {
+
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) s16x4* lds_s16x4_ptr;
+
+__device__ __forceinline__ u32x2 tr_read(const unsigned char* p) {
+    return __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)p));
+}
+
+constexpr int WTH = 8;
+
+template <int KH, int KW, bool S2>
+struct WGeo {
+    static constexpr int TWG = S2 ? 32 : 64;
+    static constexpr int XH = S2 ? 2 * WTH : WTH + KH - 1;
+    static constexpr int XW = S2 ? 2 * TWG : TWG + KW - 1;
+    static constexpr int XPIX = XH * XW, GPIX = WTH * TWG, TAPS = KH * KW;
+    static constexpr int LDS = 2 * (XPIX + GPIX) * 64;
+};
+
+template <int KH, int KW, bool S2>
+__global__ __launch_bounds__(256, 1) void bwgrad_kernel(mgx_conv_desc d, const bf16_t* __restrict__ x,
+                                                        const bf16_t* __restrict__ g, float* __restrict__ partial,
+                                                        long ntiles, int tiles_h, int tiles_w, int chunks) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    using G = WGeo<KH, KW, S2>;
+    constexpr int TWG = G::TWG, XW = G::XW, XPIX = G::XPIX, GPIX = G::GPIX, TAPS = G::TAPS;
+    constexpr int XITER = (XPIX * 4 + 255) / 256, GITER = (GPIX * 4 + 255) / 256;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wvs = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int Hx = d.hin, Wx = d.win, Hg = d.hout, Wg = d.wout;
+    const int chunk = (blockIdx.x >> 3) % chunks;
+    const int slot = (blockIdx.x & 7) + 8 * (blockIdx.x / (8 * chunks));
+    const int nslots = gridDim.x / chunks;
+    const int xc0 = d.cin > 32 ? chunk * 32 : 0, gc0 = d.ngemm > 32 ? chunk * 32 : 0;
+    unsigned char* xbuf = lds;                       // [2][XPIX][64 B]
+    unsigned char* gbuf = lds + 2 * XPIX * 64;       // [2][GPIX][64 B]
+
+    auto tile_of = [&](long t, long& img, int& h0, int& w0) {
+        const unsigned per_img = (unsigned)(tiles_h * tiles_w);
+        const unsigned tu = (unsigned)t;
+        const unsigned im = tu / per_img;
+        const unsigned rem = tu - im * per_img;
+        const unsigned th = rem / (unsigned)tiles_w;
+        img = im;
+        h0 = (int)th * WTH;
+        w0 = (int)(rem - th * tiles_w) * TWG;
+    };
+    const int q4 = tid & 3;
+    u32x4 sx[XITER], sg[GITER];
+    auto stage_load = [&](long t) {
+        long img; int h0, w0;
+        tile_of(t, img, h0, w0);
+        // x window
+        const int hb = S2 ? 2 * h0 : h0 - d.pt, wb = S2 ? 2 * w0 : w0 - d.pl;
+        const long xband = ((img * Hx + hb) * (long)Wx) * d.cin;
+        const unsigned xbytes = (unsigned)G::XH * Wx * d.cin * 2u;
+        const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)(x + xband), 0, xbytes, 0x00020000);
+#pragma unroll
+        for (int i = 0; i < XITER; ++i) {
+            const int px = (tid >> 2) + 64 * i;
+            const int ty = px / XW, tx = px - ty * XW;
+            const unsigned hi = (unsigned)(ty + hb), wi = (unsigned)(tx + wb);
+            const bool ok = px < XPIX && hi < (unsigned)Hx && wi < (unsigned)Wx;
+            const unsigned off = ok ? (unsigned)(((ty * Wx + (tx + wb)) * d.cin + xc0 + q4 * 8) * 2) : 0xfffffff0u;
+            sx[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, off, 0, 0));
+        }
+        // gradient tile
+        const long gband = ((img * Hg + h0) * (long)Wg) * d.ngemm;
+        const unsigned gbytes = (unsigned)WTH * Wg * d.ngemm * 2u;
+        const __amdgpu_buffer_rsrc_t rg = __builtin_amdgcn_make_buffer_rsrc((void*)(g + gband), 0, gbytes, 0x00020000);
+#pragma unroll
+        for (int i = 0; i < GITER; ++i) {
+            const int px = (tid >> 2) + 64 * i;
+            const int ty = px / TWG, tx = px - ty * TWG;
+            const bool ok = px < GPIX && (unsigned)(ty + h0) < (unsigned)Hg && (unsigned)(tx + w0) < (unsigned)Wg;
+            const unsigned off = ok ? (unsigned)(((ty * Wg + (tx + w0)) * d.ngemm + gc0 + q4 * 8) * 2) : 0xfffffff0u;
+            sg[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rg, off, 0, 0));
+        }
+    };
+    auto stage_write = [&](int b) {
+#pragma unroll
+        for (int i = 0; i < XITER; ++i) {
+            const int px = (tid >> 2) + 64 * i;
+            if (64 * (i + 1) <= XPIX || px < XPIX) *(u32x4*)(xbuf + (b * XPIX + px) * 64 + q4 * 16) = sx[i];
+        }
+#pragma unroll
+        for (int i = 0; i < GITER; ++i) {
+            const int px = (tid >> 2) + 64 * i;
+            if (64 * (i + 1) <= GPIX || px < GPIX) *(u32x4*)(gbuf + (b * GPIX + px) * 64 + q4 * 16) = sg[i];
+        }
+    };
+
+    f32x16 acc[TAPS + 1];
+#pragma unroll
+    for (int a = 0; a <= TAPS; ++a)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[a][i] = 0.f;
+    const u32x4 ones = {0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u};
+
+    // transposed-read lane geometry: 16-lane group gq = lane >> 4 serves channel block gq & 1 and k half
+    // gq >> 1; lane 4q + p of a group supplies the address of position q, channels 4p .. 4p+3
+    const int hk = lane >> 5, cb = (lane >> 4) & 1, qq = (lane >> 2) & 3, pp = lane & 3;
+    const int col_l = 8 * hk + qq;                       // + 16 ks + 4 s
+    const int ch_off = (16 * cb + 4 * pp) * 2;
+
+    long t = slot;
+    int cur = 0;
+    if (t < ntiles) {
+        stage_load(t);
+        stage_write(0);
+    }
+    __syncthreads();
+    while (t < ntiles) {
+        const long tn = t + nslots;
+        const bool has_next = tn < ntiles;
+        if (has_next) stage_load(tn);
+        const unsigned char* xb = xbuf + cur * XPIX * 64 + ch_off;
+        const unsigned char* gb = gbuf + cur * GPIX * 64 + ch_off;
+#pragma unroll
+        for (int rr = 0; rr < 2; ++rr) {
+            const int wr = 2 * wvs + rr;
+#pragma unroll
+            for (int ks = 0; ks < TWG / 16; ++ks) {
+                const int col = 16 * ks + col_l;
+                const unsigned char* gp = gb + (wr * TWG + col) * 64;
+                const u32x2 b0 = tr_read(gp), b1 = tr_read(gp + 4 * 64);
+                const u32x4 bfrag = {b0[0], b0[1], b1[0], b1[1]};
+#pragma unroll
+                for (int tap = 0; tap < TAPS; ++tap) {
+                    const int ta = tap / KW, tb = tap - ta * KW;
+                    const unsigned char* xp = S2 ? xb + ((2 * wr + ta) * XW + 2 * col + tb) * 64
+                                                 : xb + ((wr + ta) * XW + col + tb) * 64;
+                    const u32x2 a0 = tr_read(xp), a1 = tr_read(xp + (S2 ? 8 : 4) * 64);
+                    const u32x4 afrag = {a0[0], a0[1], a1[0], a1[1]};
+                    acc[tap] = mfma_bf16(afrag, bfrag, acc[tap]);
+                }
+                acc[TAPS] = mfma_bf16(ones, bfrag, acc[TAPS]);
+            }
+        }
+        if (has_next) stage_write(cur ^ 1);
+        __syncthreads();
+        cur ^= 1;
+        t = tn;
+    }
+
+    // ---- add the four waves in fixed order: (w0 + w2) + (w1 + w3), through LDS ----
+    float* red = (float*)lds;                           // [2][TAPS+1][16][64] floats <= 80 KB
+    __syncthreads();
+    if (wvs >= 2) {
+#pragma unroll
+        for (int a = 0; a <= TAPS; ++a)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) red[(((wvs - 2) * (TAPS + 1) + a) * 16 + i) * 64 + lane] = acc[a][i];
+    }
+    __syncthreads();
+    if (wvs < 2) {
+#pragma unroll
+        for (int a = 0; a <= TAPS; ++a)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[a][i] += red[((wvs * (TAPS + 1) + a) * 16 + i) * 64 + lane];
+    }
+    __syncthreads();
+    if (wvs == 1) {
+#pragma unroll
+        for (int a = 0; a <= TAPS; ++a)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) red[(a * 16 + i) * 64 + lane] = acc[a][i];
+    }
+    __syncthreads();
+    if (wvs == 0) {
+        float* dst = partial + ((long)(slot * chunks + chunk) * (TAPS + 1)) * 1024;
+#pragma unroll
+        for (int a = 0; a <= TAPS; ++a)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) dst[(a * 16 + i) * 64 + lane] = acc[a][i] + red[(a * 16 + i) * 64 + lane];
+    }
+}
+
+// dW[tap*wtap + k*wsk + n*wsn] += sum over slots of the slab element; block = 64 elements x 16 slot
+// groups (group q adds slots q, q+16, ... in order), then a fixed tree over the groups.  Elements past
+// the weights are the bias gradient (row 0 of the bias tile of chunk 0, or of every chunk when the
+// chunks split the output channels).
+__global__ __launch_bounds__(1024) void bwgrad_reduce_kernel(mgx_conv_desc d, const float* __restrict__ partial,
+                                                             float* __restrict__ dw, float* __restrict__ db,
+                                                             int nslots, int chunks, int taps) {
+    __shared__ float red[16][64];
+    const int e = threadIdx.x & 63, q = threadIdx.x >> 6;
+    const long idx = (long)blockIdx.x * 64 + e;
+    const long wtotal = (long)chunks * taps * 1024;
+    const int nb = d.ngemm;                              // bias elements
+    const long total = wtotal + (db ? nb : 0);
+    float s = 0.f;
+    long dst = -1;
+    bool is_bias = false;
+    if (idx < total) {
+        int chunk, tile, i, j;
+        if (idx < wtotal) {
+            chunk = (int)(idx / (taps * 1024));
+            const int rem = (int)(idx - (long)chunk * taps * 1024);
+            tile = rem >> 10;
+            i = (rem >> 5) & 31;
+            j = rem & 31;
+            const int k = (d.cin > 32 ? chunk * 32 : 0) + i, n = (d.ngemm > 32 ? chunk * 32 : 0) + j;
+            dst = (long)tile * d.wtap + (long)k * d.wsk + (long)n * d.wsn;
+        } else {
+            const int n = (int)(idx - wtotal);
+            chunk = d.ngemm > 32 ? n >> 5 : 0;
+            tile = taps;
+            i = 0;
+            j = n & 31;
+            dst = n;
+            is_bias = true;
+        }
+        const int lane = j + 32 * ((i >> 2) & 1), reg = (i & 3) + 4 * (i >> 3);
+        const float* src = partial + ((long)chunk * (taps + 1) + tile) * 1024 + reg * 64 + lane;
+        const long stride = (long)chunks * (taps + 1) * 1024;
+        for (int sp = q; sp < nslots; sp += 16) s += src[sp * stride];
+    }
+    red[q][e] = s;
+    __syncthreads();
+    if (q == 0 && idx < total) {
+        float t[16];
+#pragma unroll
+        for (int k = 0; k < 16; ++k) t[k] = red[k][e];
+#pragma unroll
+        for (int w = 8; w > 0; w >>= 1)
+#pragma unroll
+            for (int k = 0; k < w; ++k) t[k] += t[k + w];
+        if (is_bias) db[dst] += t[0];
+        else dw[dst] += t[0];
+    }
+}
+
+constexpr int WGRID = 256;
+
+template <int KH, int KW, bool S2>
+int launch_w(const mgx_conv_desc& d, const bf16_t* x, const bf16_t* g, float* dw, float* db, float* partial,
+             hipStream_t st) {
+    using G = WGeo<KH, KW, S2>;
+    const int chunks = (d.cin > 32 ? d.cin / 32 : 1) * (d.ngemm > 32 ? d.ngemm / 32 : 1);
+    const int tiles_h = (d.hout + WTH - 1) / WTH, tiles_w = (d.wout + G::TWG - 1) / G::TWG;
+    const long ntiles = (long)d.nimg * tiles_h * tiles_w;
+    if (ntiles <= 0 || ntiles >= (1L << 31)) return MGX_ERR_ARG;
+    if (hipFuncSetAttribute((const void*)bwgrad_kernel<KH, KW, S2>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                            G::LDS) != hipSuccess)
+        return MGX_ERR_LAUNCH;
+    hipLaunchKernelGGL((bwgrad_kernel<KH, KW, S2>), dim3(WGRID), dim3(256), G::LDS, st, d, x, g, partial, ntiles,
+                       tiles_h, tiles_w, chunks);
+    const int nslots = WGRID / chunks;
+    const long total = (long)chunks * G::TAPS * 1024 + (db ? d.ngemm : 0);
+    hipLaunchKernelGGL(bwgrad_reduce_kernel, dim3((unsigned)((total + 63) / 64)), dim3(1024), 0, st, d, partial, dw, db,
+                       nslots, chunks, G::TAPS);
+    return mgx_launch_status();
+}
+
+int wgrad_taps(const mgx_conv_desc& d) { return d.kh * d.kw; }
+
+}  // namespace
+
+extern "C" int mgx_conv_bf16_supported(const mgx_conv_desc* d);
+
+// Bytes of workspace mgx_conv_wgrad_bf16 needs for d (0: unsupported descriptor).
+extern "C" int64_t mgx_conv_wgrad_bf16_workspace(const mgx_conv_desc* d) {
+    if (!d || !mgx_conv_bf16_supported(d) || d->dkh != 1 || d->flip) return 0;
+    return (int64_t)WGRID * (wgrad_taps(*d) + 1) * 1024 * 4;
+}
+
+extern "C" int mgx_conv_wgrad_bf16(const mgx_conv_desc* dp, const void* x, const void* g, float* dw, float* dbias,
+                                   void* workspace, int64_t workspace_bytes, void* stream) {
+    if (!dp || !x || !g || !dw || !workspace) return MGX_ERR_ARG;
+    const int64_t need = mgx_conv_wgrad_bf16_workspace(dp);
+    if (need == 0) return MGX_ERR_ARG;
+    if (workspace_bytes < need) return MGX_ERR_WORKSPACE;
+    if (dbias && dp->nbias != dp->ngemm) return MGX_ERR_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    const bf16_t* xb = (const bf16_t*)x;
+    const bf16_t* gb = (const bf16_t*)g;
+    float* part = (float*)workspace;
+    const mgx_conv_desc& d = *dp;
+    if (d.sh == 2) return launch_w<2, 2, true>(d, xb, gb, dw, dbias, part, st);
+    if (d.kh == 3) return launch_w<3, 3, false>(d, xb, gb, dw, dbias, part, st);
+    if (d.kh == 2) return launch_w<2, 2, false>(d, xb, gb, dw, dbias, part, st);
+    return launch_w<1, 1, false>(d, xb, gb, dw, dbias, part, st);
+}

@@ -468,3 +468,122 @@ def adam_multi(p_table, n_table, off_table, g_flat, v_flat, blk_tensor, blk_star
     check(_lib().mgx_adam_multi(p_table.data_ptr(), n_table.data_ptr(), off_table.data_ptr(), _p(g_flat), _p(v_flat),
                                 blk_tensor.data_ptr(), blk_start.data_ptr(), nblocks, float(lr_t), float(beta2),
                                 float(eps), K.stream_ptr()), "mgx_adam_multi")
+
+
+# --------------------------------------------------------------------------------------------
+# bf16 path: 32 / 128-channel discriminator activations in bfloat16, float32 accumulation
+# --------------------------------------------------------------------------------------------
+def _pb(t: Optional[torch.Tensor]):
+    if t is None:
+        return None
+    if t.dtype != torch.bfloat16 or not t.is_cuda or not t.is_contiguous():
+        raise MgxError("operand must be a contiguous bfloat16 device tensor")
+    return t.data_ptr()
+
+
+def conv_bf16_supported(d: ConvDesc) -> bool:
+    return bool(_lib().mgx_conv_bf16_supported(C.byref(d)))
+
+
+def _conv_bytes_bf16(d: ConvDesc, n_in: int = 1, n_out: int = 1) -> float:
+    xe, ye, we = _conv_sizes(d)
+    return 2.0 * (n_in * xe + n_out * ye) + 4.0 * (we + d.nbias)
+
+
+def conv_gemm_bf16(d: ConvDesc, x, w, bias, y, dact=None, ymul=None, act_alpha=0.0):
+    """mgx_conv_gemm_bf16: x, y (and dact, ymul) bfloat16; w, bias float32."""
+    xe, ye, we = _conv_sizes(d)
+    if x.numel() != xe or y.numel() != ye or w.numel() < we:
+        raise MgxError("conv_gemm_bf16: operand sizes do not match the descriptor")
+    for t in (dact, ymul):
+        if t is not None and t.numel() != ye:
+            raise MgxError("conv_gemm_bf16: dact / ymul size mismatch")
+    if d.nbias and (bias is None or bias.numel() != d.nbias):
+        raise MgxError("conv_gemm_bf16: bias size mismatch")
+    d.accumulate = 0
+    d.act_alpha = float(act_alpha)
+    e0 = PROFILER.start() if PROFILER is not None else None
+    check(_lib().mgx_conv_gemm_bf16(C.byref(d), _pb(x), _p(w), _p(bias) if d.nbias else None, _pb(y), _pb(dact),
+                                    _pb(ymul), K.stream_ptr()), "mgx_conv_gemm_bf16")
+    if e0 is not None:
+        kk = 1 if (d.sh == 2 or d.dkh == 2) else d.kh
+        key = "bconv_kernel<%d,%d,%d>" % (kk, kk, 2 if ymul is not None else (1 if (d.nbias or act_alpha > 0) else 0))
+        PROFILER.stop(key, _conv_flops(d), e0,
+                      _conv_bytes_bf16(d, 1, 1 + (1 if dact is not None else 0) + (1 if ymul is not None else 0)))
+
+
+def conv_wgrad_bf16(d: ConvDesc, x, g, dw, dbias):
+    xe, ye, we = _conv_sizes(d)
+    if x.numel() != xe or g.numel() != ye or dw.numel() < we:
+        raise MgxError("conv_wgrad_bf16: operand sizes do not match the descriptor")
+    if dbias is not None and dbias.numel() != d.nbias:
+        raise MgxError("conv_wgrad_bf16: bias gradient size mismatch")
+    lib = _lib()
+    nbytes = lib.mgx_conv_wgrad_bf16_workspace(C.byref(d))
+    if nbytes <= 0:
+        raise MgxError("conv_wgrad_bf16: unsupported descriptor")
+    ws = K.workspace(nbytes)
+    e0 = PROFILER.start() if PROFILER is not None else None
+    check(lib.mgx_conv_wgrad_bf16(C.byref(d), _pb(x), _pb(g), _p(dw), _p(dbias), ws.data_ptr(), ws.numel(),
+                                  K.stream_ptr()), "mgx_conv_wgrad_bf16")
+    if e0 is not None:
+        PROFILER.stop("bwgrad_kernel<%d,%d>" % (d.kh, d.kw), _conv_flops(d), e0, _conv_bytes_bf16(d, 1, 1))
+
+
+@_hbm_op("pointwise2_bf16_fwd")
+def pointwise2_bf16_fwd(x, w, bias, y, dact, npos, act_alpha):
+    if x.numel() != 2 * npos or y.numel() != 128 * npos or w.numel() != 256 or (bias is not None and bias.numel() != 128) \
+            or (dact is not None and dact.numel() != y.numel()):
+        raise MgxError("pointwise2_bf16_fwd: size mismatch")
+    check(_lib().mgx_pointwise2_bf16_fwd(_p(x), _p(w), _p(bias), _pb(y), _pb(dact), npos, float(act_alpha),
+                                         K.stream_ptr()), "mgx_pointwise2_bf16_fwd")
+
+
+@_hbm_op("pointwise2_bf16_wgrad")
+def pointwise2_bf16_wgrad(x, g, dw, db, npos):
+    if x.numel() != 2 * npos or g.numel() != 128 * npos or dw.numel() != 256 or (db is not None and db.numel() != 128):
+        raise MgxError("pointwise2_bf16_wgrad: size mismatch")
+    lib = _lib()
+    ws = K.workspace(lib.mgx_pointwise2_bf16_wgrad_workspace(npos))
+    check(lib.mgx_pointwise2_bf16_wgrad(_p(x), _pb(g), _p(dw), _p(db), ws.data_ptr(), ws.numel(), npos,
+                                        K.stream_ptr()), "mgx_pointwise2_bf16_wgrad")
+
+
+@_hbm_op("pointwise_to2_bf16")
+def pointwise_to2_bf16(g, w, dx, npos, accumulate):
+    if g.numel() != 128 * npos or dx.numel() != 2 * npos or w.numel() != 256:
+        raise MgxError("pointwise_to2_bf16: size mismatch")
+    check(_lib().mgx_pointwise_to2_bf16(_pb(g), _p(w), _p(dx), npos, int(accumulate), K.stream_ptr()),
+          "mgx_pointwise_to2_bf16")
+
+
+@_hbm_op("wsum_bf16_fwd")
+def weighted_sum_bf16_fwd(a, b, alpha, y):
+    if a.numel() != b.numel() or a.numel() != y.numel() or alpha.numel() != 1:
+        raise MgxError("weighted_sum_bf16_fwd: size mismatch")
+    check(_lib().mgx_weighted_sum_bf16_fwd(_pb(a), _pb(b), _p(alpha), _pb(y), y.numel(), K.stream_ptr()),
+          "mgx_weighted_sum_bf16_fwd")
+
+
+@_hbm_op("wsum_bf16_bwd")
+def weighted_sum_bf16_bwd(dy, a, b, alpha, da, db, dalpha):
+    n = dy.numel()
+    for t in (a, b, da, db):
+        if t is not None and t.numel() != n:
+            raise MgxError("weighted_sum_bf16_bwd: size mismatch")
+    lib = _lib()
+    ws = K.workspace(lib.mgx_reduce_workspace())
+    check(lib.mgx_weighted_sum_bf16_bwd(_pb(dy), _pb(a), _pb(b), _p(alpha), _pb(da), _pb(db), _p(dalpha),
+                                        ws.data_ptr(), ws.numel(), n, K.stream_ptr()), "mgx_weighted_sum_bf16_bwd")
+
+
+def cast_to_bf16(x: torch.Tensor) -> torch.Tensor:
+    y = torch.empty(x.shape, dtype=torch.bfloat16, device=x.device)
+    check(_lib().mgx_cast_f32_to_bf16(_p(x), _pb(y), x.numel(), K.stream_ptr()), "mgx_cast_f32_to_bf16")
+    return y
+
+
+def cast_to_f32(x: torch.Tensor) -> torch.Tensor:
+    y = torch.empty(x.shape, dtype=torch.float32, device=x.device)
+    check(_lib().mgx_cast_bf16_to_f32(_pb(x), _p(y), x.numel(), K.stream_ptr()), "mgx_cast_bf16_to_f32")
+    return y
