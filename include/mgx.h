@@ -305,6 +305,11 @@ int mgx_weighted_sum_bf16_fwd(const void* a, const void* b, const float* alpha, 
 int mgx_weighted_sum_bf16_bwd(const void* dy, const void* a, const void* b, const float* alpha, void* da, void* db,
                               float* dalpha, void* workspace, int64_t workspace_bytes, int64_t n, void* stream);
 
+/* out = a (.) b over n elements (n a multiple of 8): b and out bf16, a bf16 or float32 (a_is_f32): the
+ * product dY (.) f' of tf.GradientTape through a SoftRectifier (models.py:205-206) where the kernel that
+ * produced dY could not apply the saved derivative itself. */
+int mgx_mul_bf16(const void* a, int a_is_f32, const void* b, void* out, int64_t n, void* stream);
+
 /* Casts at the boundary between the bf16 grow blocks and the float32 base block (no counterpart in the
  * reference, which runs float32 throughout). */
 int mgx_cast_f32_to_bf16(const float* x, void* y, int64_t n, void* stream);

@@ -104,6 +104,31 @@ def get_value(var: Variable):
     return var.numpy()
 
 
+# Arithmetic of the discriminator's grow blocks: "float32" (v_mfma_f32_32x32x2_f32 everywhere) or
+# "bfloat16" (32 / 128-channel activations at 8 rows and more stored as bf16, bf16 MFMA with float32
+# accumulation; weights, gradients of variables, 2-channel audio tensors and the 4 x 750 base block stay
+# float32).
+_precision = ["float32"]
+BF16_MIN_ROWS = 8
+
+
+def set_precision(name: str):
+    if name in ("bf16", "bfloat16"):
+        _precision[0] = "bfloat16"
+    elif name in ("fp32", "f32", "float32"):
+        _precision[0] = "float32"
+    else:
+        raise ValueError("precision must be 'float32' or 'bfloat16'")
+
+
+def precision() -> str:
+    return _precision[0]
+
+
+def bf16_enabled() -> bool:
+    return _precision[0] == "bfloat16"
+
+
 _workspace: Dict[int, torch.Tensor] = {}
 
 
@@ -139,8 +164,8 @@ def side_buffers(nfloats: int):
     return cur
 
 
-def empty(shape, dev=None) -> torch.Tensor:
-    return torch.empty(tuple(int(s) for s in shape), dtype=torch.float32, device=dev or device())
+def empty(shape, dev=None, dtype=torch.float32) -> torch.Tensor:
+    return torch.empty(tuple(int(s) for s in shape), dtype=dtype, device=dev or device())
 
 
 def zeros(shape, dev=None) -> torch.Tensor:

@@ -41,6 +41,30 @@ __global__ __launch_bounds__(kBlock) void cast_b2f_kernel(const bf16_t* __restri
     if (t < n) y[t] = (float)x[t];
 }
 
+// out = a (.) b with b, out bf16 and a bf16 or float32: dY (.) f'(pre-activation) where the data-gradient
+// kernel upstream could not apply the multiplier itself.
+template <bool AF32>
+__global__ __launch_bounds__(kBlock) void mul_b_kernel(const void* __restrict__ a, const bf16_t* __restrict__ b,
+                                                       bf16_t* __restrict__ out, long n8) {
+    for (long i = (long)blockIdx.x * kBlock + threadIdx.x; i < n8; i += (long)gridDim.x * kBlock) {
+        const u32x4 bv = ((const u32x4*)b)[i];
+        float av[8];
+        if (AF32) {
+            const f32x4 a0 = ((const f32x4*)a)[2 * i], a1 = ((const f32x4*)a)[2 * i + 1];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { av[k] = a0[k]; av[4 + k] = a1[k]; }
+        } else {
+            const u32x4 v = ((const u32x4*)a)[i];
+#pragma unroll
+            for (int k = 0; k < 4; ++k) { av[2 * k] = bf_lo(v[k]); av[2 * k + 1] = bf_hi(v[k]); }
+        }
+        u32x4 o;
+#pragma unroll
+        for (int k = 0; k < 4; ++k) o[k] = bf_pack(av[2 * k] * bf_lo(bv[k]), av[2 * k + 1] * bf_hi(bv[k]));
+        ((u32x4*)out)[i] = o;
+    }
+}
+
 // ---------------- from-audio 1x1 convolution: 2 float32 channels -> 128 bf16 channels ----------------
 // 16 lanes per position, 8 output channels (16 bytes) each; the lane's 24 weights / biases stay in registers.
 template <bool ACT, bool DER>
@@ -229,6 +253,18 @@ extern "C" int mgx_cast_bf16_to_f32(const void* x, float* y, int64_t n, void* st
     const long n8 = n / 8;
     hipLaunchKernelGGL(cast_b2f_kernel, dim3(grid_for(n8 > 0 ? n8 : 1)), dim3(kBlock), 0, (hipStream_t)stream,
                        (const bf16_t*)x, y, n8, (long)n);
+    return mgx_launch_status();
+}
+
+extern "C" int mgx_mul_bf16(const void* a, int a_is_f32, const void* b, void* out, int64_t n, void* stream) {
+    if (!a || !b || !out || n <= 0 || n % 8) return MGX_ERR_ARG;
+    const long n8 = n / 8;
+    if (a_is_f32)
+        hipLaunchKernelGGL((mul_b_kernel<true>), dim3(grid_for(n8)), dim3(kBlock), 0, (hipStream_t)stream, a,
+                           (const bf16_t*)b, (bf16_t*)out, n8);
+    else
+        hipLaunchKernelGGL((mul_b_kernel<false>), dim3(grid_for(n8)), dim3(kBlock), 0, (hipStream_t)stream, a,
+                           (const bf16_t*)b, (bf16_t*)out, n8);
     return mgx_launch_status();
 }
 

@@ -285,6 +285,19 @@ class Model:
             self._plan_infer = plan
         self._last_use_infer = self._compute_last_use(self._plan_infer)
 
+    def _plan_links(self, plan):
+        """(index of the step that produces each tensor, number of steps that consume it) for a plan."""
+        cache = self.__dict__.setdefault("_links", {})
+        hit = cache.get(id(plan))
+        if hit is None:
+            producer = {id(op.output): i for i, op in enumerate(plan)}
+            n_consumers: Dict[int, int] = {}
+            for op in plan:
+                for t in op.inputs:
+                    n_consumers[id(t)] = n_consumers.get(id(t), 0) + 1
+            hit = cache[id(plan)] = (producer, n_consumers)
+        return hit
+
     @staticmethod
     def _compute_last_use(plan):
         last_use: Dict[int, int] = {}
@@ -421,6 +434,7 @@ class Model:
         Returns the gradient w.r.t. the model input (or None)."""
         grads: Dict[int, Tuple[torch.Tensor, bool]] = {id(self.output): (dy, False)}
         plan = getattr(tape, "plan", None) or self._plan
+        producer, n_consumers = self._plan_links(plan)
         for i in range(len(plan) - 1, -1, -1):
             op = plan[i]
             g = grads.pop(id(op.output), None)
@@ -446,6 +460,13 @@ class Model:
                     res = [(existing[0], True)]
                 else:
                     res = [(dx, True)]
+            elif getattr(op.node.layer, "fusable_activation", False):
+                # the data-gradient kernel of a contraction can multiply its result by the saved
+                # activation derivative of the layer that produced its input (single consumer only)
+                j = producer.get(id(op.inputs[0]))
+                outmul = tape[j] if (j is not None and n_consumers.get(id(op.inputs[0])) == 1
+                                     and hasattr(tape[j], "premultiplied")) else None
+                res = op.node.layer.backward(tape[i], g[0], need, existing, need_weight_grads, outmul=outmul)
             else:
                 res = op.node.layer.backward(tape[i], g[0], need, existing, need_weight_grads)
             tape[i] = None

@@ -93,15 +93,24 @@ class _Contraction(Layer):
     def forward(self, xs, save, act_alpha: float = 0.0):
         x = xs[0]
         n, h, w, _ = x.shape
+        mode = self._bf16_mode(x, n, h, w)
+        if mode is not None:
+            return self._forward_bf16(mode, x, save, act_alpha)
+        was_bf16 = x.dtype == torch.bfloat16
+        if was_bf16:                       # this layer has no bf16 kernel: leave the bf16 region here
+            x = ops.cast_to_f32(x)
         ho, wo = self._out_hw(h, w)
         y = K.empty((n, ho, wo, self.filters))
         dact = K.empty(y.shape) if (save and act_alpha > 0.0) else None
         ops.conv_gemm(self._desc("f", n, h, w), x, self.kernel.value(), self.bias.value(), y,
                       dact=dact, act_alpha=act_alpha)
-        return y, ((x, dact) if save else None)
+        return y, ((_CastSaved((x, dact)) if was_bf16 else (x, dact)) if save else None)
 
-    def backward(self, saved, dy, need, existing, wgrad):
+    def backward(self, saved, dy, need, existing, wgrad, outmul=None):
+        if isinstance(saved, _BSaved):
+            return self._backward_bf16(saved, dy, need, existing, wgrad, outmul)
         x, dact = saved
+        was_bf16 = isinstance(saved, _CastSaved)
         n, h, w, _ = x.shape
         if wgrad and self.trainable:
             if self.kernel.grad is None or self.bias.grad is None:
@@ -109,10 +118,86 @@ class _Contraction(Layer):
             ops.conv_wgrad(self._desc("f", n, h, w), x, dy, self.kernel.grad, self.bias.grad, dymul=dact)
         if not need[0]:
             return [None]
+        if was_bf16:
+            if existing[0] is not None:
+                raise NotImplementedError("gradient fan-in into a bf16 activation")
+            dx = K.empty(x.shape)
+            ops.conv_gemm(self._desc("d", n, h, w), dy, self.kernel.value(), None, dx, xmul=dact)
+            return [(ops.cast_to_bf16(dx), True)]
         dx = existing[0] if existing[0] is not None else K.empty(x.shape)
         ops.conv_gemm(self._desc("d", n, h, w), dy, self.kernel.value(), None, dx, xmul=dact,
                       accumulate=existing[0] is not None)
         return [(dx, True)]
+
+    # ---- bf16 path (discriminator grow blocks) ----
+    def _bf16_mode(self, x, n, h, w):
+        """None, "conv" (bf16 tile kernels) or "audio" (2 float32 channels -> 128 bf16 channels)."""
+        if not K.bf16_enabled() or x.dim() != 4 or h < K.BF16_MIN_ROWS or not isinstance(self, Conv2D):
+            return None
+        if x.dtype == torch.bfloat16:
+            return "conv" if ops.conv_bf16_supported(self._desc("f", n, h, w)) else None
+        if self.cin == 2 and self.filters == 128 and self.kernel_size == (1, 1):
+            return "audio"
+        return None
+
+    def _forward_bf16(self, mode, x, save, act_alpha):
+        n, h, w, _ = x.shape
+        ho, wo = self._out_hw(h, w)
+        y = K.empty((n, ho, wo, self.filters), dtype=torch.bfloat16)
+        dact = K.empty(y.shape, dtype=torch.bfloat16) if (save and act_alpha > 0.0) else None
+        if mode == "audio":
+            ops.pointwise2_bf16_fwd(x, self.kernel.value(), self.bias.value(), y, dact, n * h * w, act_alpha)
+        else:
+            ops.conv_gemm_bf16(self._desc("f", n, h, w), x, self.kernel.value(), self.bias.value(), y, dact=dact,
+                               act_alpha=act_alpha)
+        return y, (_BSaved(mode, x, dact) if save else None)
+
+    def _backward_bf16(self, saved, dy, need, existing, wgrad, outmul):
+        x = saved.x
+        n, h, w, _ = x.shape
+        if saved.dact is not None and not saved.premultiplied:
+            g = ops.mul_bf16(dy, saved.dact)          # dY (.) f': the kernel upstream could not apply it
+        else:
+            g = dy if dy.dtype == torch.bfloat16 else ops.cast_to_bf16(dy)
+        do_w = wgrad and self.trainable
+        if do_w and (self.kernel.grad is None or self.bias.grad is None):
+            raise RuntimeError("gradient buffers of %s are not bound" % self.name)
+        if saved.mode == "audio":
+            if do_w:
+                ops.pointwise2_bf16_wgrad(x, g, self.kernel.grad, self.bias.grad, n * h * w)
+            if not need[0]:
+                return [None]
+            dx = existing[0] if existing[0] is not None else K.empty(x.shape)
+            ops.pointwise_to2_bf16(g, self.kernel.value(), dx, n * h * w, existing[0] is not None)
+            return [(dx, True)]
+        if do_w:
+            ops.conv_wgrad_bf16(self._desc("f", n, h, w), x, g, self.kernel.grad, self.bias.grad)
+        if not need[0]:
+            return [None]
+        if existing[0] is not None:
+            raise NotImplementedError("gradient fan-in into a bf16 activation")
+        dx = K.empty(x.shape, dtype=torch.bfloat16)
+        ymul = None
+        if outmul is not None and outmul.dact is not None and not outmul.premultiplied:
+            ymul = outmul.dact
+            outmul.premultiplied = True      # the producer of x receives dX (.) f' and must not multiply again
+        ops.conv_gemm_bf16(self._desc("d", n, h, w), g, self.kernel.value(), None, dx, ymul=ymul)
+        return [(dx, True)]
+
+
+class _CastSaved(tuple):
+    """(x, dact) of a float32 contraction whose input arrived as bf16 and was cast: the data-gradient goes
+    back as bf16."""
+
+
+class _BSaved:
+    """Tape entry of a contraction that ran on the bf16 kernels: its input, the saved derivative of the
+    fused activation (or None) and whether the gradient that will arrive has already been multiplied
+    by that derivative (the data-gradient kernel of the consuming layer does it in its epilogue)."""
+    __slots__ = ("mode", "x", "dact", "premultiplied")
+
+    def __init__(self, mode, x, dact):
+        self.mode, self.x, self.dact, self.premultiplied = mode, x, dact, False
 
 
 class Conv2D(_Contraction):
@@ -261,7 +346,7 @@ class Dense(_Contraction):
         y4, saved = super().forward([x.view(n, 1, 1, e)], save, act_alpha)
         return y4.view(n, self.units), saved
 
-    def backward(self, saved, dy, need, existing, wgrad):
+    def backward(self, saved, dy, need, existing, wgrad, outmul=None):
         if len(saved) == 2:
             x, _ = saved
             if x.dim() == 4 and dy.dim() == 4:

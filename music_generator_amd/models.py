@@ -41,8 +41,15 @@ class WeightedSum(Add):
 
     def _merge_function(self, inputs):
         assert len(inputs) == 2                                   # models.py:32
-        y = K.empty(inputs[0].shape)
-        ops.weighted_sum_fwd(inputs[0], inputs[1], self.alpha.value(), y)
+        a, b = inputs
+        if a.dtype != b.dtype:            # one side left the bf16 region: blend in float32
+            a = a if a.dtype == torch.float32 else ops.cast_to_f32(a)
+            b = b if b.dtype == torch.float32 else ops.cast_to_f32(b)
+        y = K.empty(a.shape, dtype=a.dtype)
+        if a.dtype == torch.bfloat16:
+            ops.weighted_sum_bf16_fwd(a, b, self.alpha.value(), y)
+        else:
+            ops.weighted_sum_fwd(a, b, self.alpha.value(), y)
         return y
 
     def forward(self, xs, save):
@@ -50,16 +57,32 @@ class WeightedSum(Add):
 
     def backward(self, saved, dy, need, existing, wgrad):
         a, b = saved
+        dalpha = self.alpha.grad if (wgrad and self.trainable and self.alpha.trainable) else None
+        if dalpha is None and wgrad and self.trainable and self.alpha.trainable:
+            raise RuntimeError("gradient buffer of %s is not bound" % self.alpha.name)
+        if a.dtype == torch.bfloat16 and b.dtype == torch.bfloat16:
+            if existing[0] is not None or existing[1] is not None:
+                raise NotImplementedError("gradient fan-in into a bf16 activation")
+            g = dy if dy.dtype == torch.bfloat16 else ops.cast_to_bf16(dy)
+            da = K.empty(a.shape, dtype=torch.bfloat16) if need[0] else None
+            db = K.empty(b.shape, dtype=torch.bfloat16) if need[1] else None
+            ops.weighted_sum_bf16_bwd(g, a, b, self.alpha.value(), da, db, dalpha)
+            return [(da, True) if da is not None else None, (db, True) if db is not None else None]
+        mixed = (a.dtype, b.dtype)
+        if a.dtype != b.dtype:
+            a = a if a.dtype == torch.float32 else ops.cast_to_f32(a)
+            b = b if b.dtype == torch.float32 else ops.cast_to_f32(b)
         da = db = None
         if need[0]:
             da = existing[0] if existing[0] is not None else K.empty(a.shape)
         if need[1]:
             db = existing[1] if existing[1] is not None else K.empty(b.shape)
-        dalpha = self.alpha.grad if (wgrad and self.trainable and self.alpha.trainable) else None
-        if dalpha is None and wgrad and self.trainable and self.alpha.trainable:
-            raise RuntimeError("gradient buffer of %s is not bound" % self.alpha.name)
         ops.weighted_sum_bwd(dy, a, b, self.alpha.value(), da, existing[0] is not None, db,
                              existing[1] is not None, dalpha)
+        if da is not None and mixed[0] == torch.bfloat16:
+            da = ops.cast_to_bf16(da)
+        if db is not None and mixed[1] == torch.bfloat16:
+            db = ops.cast_to_bf16(db)
         return [(da, True) if da is not None else None, (db, True) if db is not None else None]
 
     def get_config(self):

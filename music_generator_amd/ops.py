@@ -577,6 +577,18 @@ def weighted_sum_bf16_bwd(dy, a, b, alpha, da, db, dalpha):
                                         ws.data_ptr(), ws.numel(), n, K.stream_ptr()), "mgx_weighted_sum_bf16_bwd")
 
 
+@_hbm_op("mul_bf16")
+def mul_bf16(a, b):
+    """bf16(a * b): a bfloat16 or float32, b bfloat16, same shape."""
+    if a.numel() != b.numel():
+        raise MgxError("mul_bf16: size mismatch")
+    out = torch.empty(b.shape, dtype=torch.bfloat16, device=b.device)
+    f32 = a.dtype == torch.float32
+    check(_lib().mgx_mul_bf16(_p(a) if f32 else _pb(a), int(f32), _pb(b), _pb(out), b.numel(), K.stream_ptr()),
+          "mgx_mul_bf16")
+    return out
+
+
 def cast_to_bf16(x: torch.Tensor) -> torch.Tensor:
     y = torch.empty(x.shape, dtype=torch.bfloat16, device=x.device)
     check(_lib().mgx_cast_f32_to_bf16(_p(x), _pb(y), x.numel(), K.stream_ptr()), "mgx_cast_f32_to_bf16")
