@@ -83,6 +83,10 @@ def main():
     ap.add_argument("--graph", action="store_true",
                     help="replay the step as one HIP graph (WGAN.use_graph): for small batches, where the host's "
                          "launch rate bounds the step; no per-kernel roofline in this mode")
+    ap.add_argument("--precision", default="float32", choices=["float32", "bfloat16"],
+                    help="bfloat16: 32/128-channel discriminator activations stored as bf16, bf16 MFMA, f32 accumulation")
+    ap.add_argument("--micro-batch", type=int, default=0, help="samples per micro-batch (multiple of 4; 0 = whole batch)")
+    ap.add_argument("--kernels", action="store_true", help="also print the per-kernel time table of the timed steps")
     ap.add_argument("--host-input", action="store_true",
                     help="hand every step a host (numpy) batch, so the host-to-device copy is inside the timed "
                          "region: the PCIe-inclusive rate, not the headline value")
@@ -107,6 +111,7 @@ def main():
     torch.cuda.set_device(local_rank % torch.cuda.device_count() if backend != "nccl" else local_rank)
     dist = DataParallel(backend=backend) if world > 1 else None
 
+    M.backend.set_precision(args.precision)
     stage, fade = args.stage, (not args.straight and args.stage > 0)
     n_blocks = stage + 1
     M.clear_session()
@@ -116,6 +121,8 @@ def main():
     gan = comp[stage][1 if fade else 0]
     gan.dist = dist
     gan.reuse_real_logits = args.reuse_real_logits
+    if args.micro_batch:
+        gan.micro_batch = args.micro_batch
     if args.graph:
         if world > 1:
             raise SystemExit("--graph is a single-GPU mode")
@@ -175,6 +182,10 @@ def main():
                           "last_metrics": last}))
         return
     summ = prof.summary()
+    if args.kernels:
+        for k, v in sorted(summ.items(), key=lambda kv: -kv[1][1]):
+            print("%-40s n=%5d  %9.2f ms  %7.1f TFLOP/s  %7.1f GB/s" % (k, v[0], v[1], v[2] / max(v[1], 1e-9) / 1e9,
+                                                                      v[3] / max(v[1], 1e-9) / 1e6), file=sys.stderr)
     # bandwidth-bound kernels (zero FLOPs recorded): achieved GB/s against the 8 TB/s HBM peak
     hbm_ops = {k: {"launches": v[0], "ms": round(v[1], 3), "GB/s": round(v[3] / v[1] / 1e6, 1),
                    "frac_of_8TBps": round(v[3] / v[1] / 1e6 / 8000.0, 3)}

@@ -294,7 +294,12 @@ def _register_fused_block(block_end, upsampling, for_sum_layer):
         w = weights()
         n, hl, wl, _ = x.shape
         y = K.empty((n, 2 * hl, 2 * wl, 2))
-        ops.gblock_fwd(w, state["pack"], x, y, n, hl, wl)
+        if K.bf16_enabled():
+            if "packb" not in state:
+                state["packb"] = torch.empty((ops.gblock_pack_bf16_bytes(),), dtype=torch.uint8, device=x.device)
+            ops.gblock_fwd_bf16(w, state["packb"], x, y, n, hl, wl)
+        else:
+            ops.gblock_fwd(w, state["pack"], x, y, n, hl, wl)
         return y
 
     def run_save(x):

@@ -577,6 +577,22 @@ def weighted_sum_bf16_bwd(dy, a, b, alpha, da, db, dalpha):
                                         ws.data_ptr(), ws.numel(), n, K.stream_ptr()), "mgx_weighted_sum_bf16_bwd")
 
 
+def gblock_pack_bf16_bytes() -> int:
+    return int(_lib().mgx_gblock_pack_bf16_bytes())
+
+
+def gblock_fwd_bf16(weights, packb, x, y, nimg, hl, wl):
+    """Tape-free forward of a generator grow block on bf16 MFMAs: x (nimg,hl,wl,2) -> y (nimg,2hl,2wl,2), float32."""
+    if x.numel() != nimg * hl * wl * 2 or y.numel() != 4 * x.numel() or packb.numel() * packb.element_size() < gblock_pack_bf16_bytes():
+        raise MgxError("gblock_fwd_bf16: size mismatch")
+    e0 = PROFILER.start() if PROFILER is not None else None
+    check(_lib().mgx_gblock_fwd_bf16(C.byref(weights), packb.data_ptr(), _p(x), _p(y), nimg, hl, wl, K.stream_ptr()),
+          "mgx_gblock_fwd_bf16")
+    if e0 is not None:
+        n = nimg * hl * wl
+        PROFILER.stop("gblock_fwd_bf16_kernel", GBLOCK_FLOP_PER_POSITION * n, e0, 4.0 * 10 * n)
+
+
 @_hbm_op("mul_bf16")
 def mul_bf16(a, b):
     """bf16(a * b): a bfloat16 or float32, b bfloat16, same shape."""
