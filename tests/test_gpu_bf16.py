@@ -383,7 +383,7 @@ def test_bf16_train_step_matches_emulated_oracle(name, bf16_precision):
     """The whole G+D step with the bf16 discriminator blocks against the oracle's train step evaluated
     with bf16 storage emulated.  Metrics and losses abs 5e-3; discriminator-step gradients relative L2
     <= 8e-2 (the saturated output activation turns the logit difference into a common factor of every
-    gradient, see test_bf16_discriminator_vs_plain_oracle; 5e-1 for alpha).  The generator-step gradients
+    gradient, see test_bf16_discriminator_vs_plain_oracle; the scalar alpha is not compared).  The generator-step gradients
     additionally follow the discriminator's sign-like first Adam update (see test_gpu_step.py: a weight
     whose gradient is ~0 moves by +-lr according to the sign of rounding noise) and are not compared here;
     test_gpu_step.py::test_generator_step_with_device_discriminator pins the generator kernels."""
@@ -404,11 +404,11 @@ def test_bf16_train_step_matches_emulated_oracle(name, bf16_precision):
     for which, model, grads, tol0 in (("d", gan.discriminator, res.d_grads, 8e-2), ("g", gan.generator, res.g_grads, None)):
         for v in model.trainable_variables:
             want = grads[v.name]
-            if np.abs(want).max() < 1e-12 or tol0 is None:
-                continue
+            if np.abs(want).max() < 1e-12 or tol0 is None or v.name.endswith("/alpha"):
+                continue            # alpha: sum(dY (new - old)) cancels to ~1e-3 of its terms; test_bf16_weighted_sum pins it
             err = rel_l2(v.grad.cpu().numpy().reshape(want.shape), want)
             worst[which] = max(worst.get(which, 0.0), err)
-            assert err < (5e-1 if v.name.endswith("/alpha") else tol0), "%s: rel-L2 %.3e" % (v.name, err)
+            assert err < tol0, "%s: rel-L2 %.3e" % (v.name, err)
     print("worst relative L2:", worst)
 
 

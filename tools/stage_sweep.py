@@ -23,9 +23,17 @@ ap = argparse.ArgumentParser()
 ap.add_argument("--stages", default="0,1,2,3,4,5")
 ap.add_argument("--steps", type=int, default=2)
 ap.add_argument("--fade", action="store_true")
+ap.add_argument("--precision", default="float32")
+ap.add_argument("--batch", type=int, default=0, help="override the batch of every listed stage")
+ap.add_argument("--micro-batch", type=int, default=0)
 args = ap.parse_args()
+M.backend.set_precision(args.precision)
 for stage in [int(s) for s in args.stages.split(",")]:
     batch, mb = PLAN[stage]
+    if args.batch:
+        batch = args.batch
+    if args.micro_batch:
+        mb = args.micro_batch
     M.clear_session()
     torch.cuda.empty_cache()
     torch.cuda.reset_peak_memory_stats()
@@ -49,7 +57,7 @@ for stage in [int(s) for s in args.stages.split(",")]:
     dt = (time.perf_counter() - t0) / args.steps
     print(json.dumps({"stage": stage, "hw": [h, w], "batch": batch, "micro_batch": mb, "generator_chunk": GEN_CHUNK.get(stage),
                       "side_budget_gib": (SIDE_BUDGET[stage] >> 30) if stage in SIDE_BUDGET else None,
-                      "fade_in": fade,
+                      "fade_in": fade, "precision": args.precision,
                       "ms_per_step": round(dt * 1e3, 2), "samples_per_s": round(batch / dt, 3),
                       "algorithmic_tflops": round(STEP_GFLOP[stage] * batch / dt / 1e3, 2),
                       "frac_f32_mfma_peak": round(STEP_GFLOP[stage] * batch / dt / 1e3 / 157.3, 4),
