@@ -186,6 +186,17 @@ int mgx_layernorm_bwd(const float* dy, const float* x, const float* gamma, const
                       float* dx, int acc_x, float* dgamma, float* dbeta,
                       int64_t nimg, int64_t e, void* workspace, int64_t workspace_bytes, void* stream);
 
+/* mgx_layernorm_fwd without a workspace argument.  No counterpart in the reference: it is for callers
+ * that cannot allocate device memory (code under HIP graph capture, tight serving loops, harnesses that
+ * forbid hipMalloc).  The partial sums go to a 32 KiB array that lives in the library's device image
+ * (one copy per GPU, held until the process ends); the call allocates and frees nothing.  Same kernels and
+ * bit-identical results as mgx_layernorm_fwd.  Limit: nimg <= mgx_layernorm_fwd_static_max_samples()
+ * (2048), otherwise MGX_ERR_WORKSPACE.  All calls on one GPU share that array: calls that overlap on one
+ * GPU (different streams) race; calls on one stream are ordered. */
+int64_t mgx_layernorm_fwd_static_max_samples(void);
+int mgx_layernorm_fwd_static(const float* x, const float* gamma, const float* beta, float* y, float* stats,
+                             int64_t nimg, int64_t e, float eps, void* stream);
+
 /* MinibatchStdDev (models.py:167-192): x (n,h,w,c) -> y (n,h+1,w,c); group g = min(4,n), sample i
  * belongs to group i % (n/g); the group statistic fills row h.  stat receives n/g floats.
  * Backward: dx = dy[:, :h] + d(stat)/dx * sum(dy[:, h]). */

@@ -80,6 +80,8 @@ PROTOTYPES = {
     "mgx_layernorm_workspace": (_I64, [_I64, _I64]),
     "mgx_layernorm_fwd": (_I, [_P, _P, _P, _P, _P, _I64, _I64, _F, _P, _I64, _P]),
     "mgx_layernorm_bwd": (_I, [_P, _P, _P, _P, _P, _I, _P, _P, _I64, _I64, _P, _I64, _P]),
+    "mgx_layernorm_fwd_static_max_samples": (_I64, []),
+    "mgx_layernorm_fwd_static": (_I, [_P, _P, _P, _P, _P, _I64, _I64, _F, _P]),
     "mgx_mbstd_workspace": (_I64, [_I64, _I64]),
     "mgx_mbstd_fwd": (_I, [_P, _P, _P, _I64, _I, _I, _I, _P, _I64, _P]),
     "mgx_mbstd_bwd": (_I, [_P, _P, _P, _I64, _I, _I, _I, _P, _I64, _P]),

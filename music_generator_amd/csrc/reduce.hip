@@ -360,6 +360,59 @@ extern "C" int mgx_layernorm_fwd(const float* x, const float* gamma, const float
     return mgx_launch_status();
 }
 
+// ------------------------------------------------------------------------------------------
+// mgx_layernorm_fwd for callers that cannot allocate (code under HIP graph capture, tight serving
+// loops): the per-(sample, block) partial sums live in a file-scope device array instead of a
+// caller workspace.  Every GPU the library runs on holds its own copy of the array (32 KiB) until the
+// process ends; the host keeps the copy's device address per GPU (the array's name in host code is
+// only a handle for hipGetSymbolAddress, never a device pointer).
+// ------------------------------------------------------------------------------------------
+constexpr int kLnStaticPairs = 2048;                 // (sample, block) pairs = 2 doubles each
+static __device__ __align__(256) double ln_static_scratch[2 * kLnStaticPairs];
+
+namespace {
+constexpr int kMaxDevices = 64;
+double* g_ln_scratch[kMaxDevices];                   // device address of the array on each GPU, once resolved
+
+int ln_static_address(double** out) {
+    int dev = -1;
+    if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= kMaxDevices) return MGX_ERR_LAUNCH;
+    double* p = __atomic_load_n(&g_ln_scratch[dev], __ATOMIC_ACQUIRE);
+    if (!p) {
+        void* addr = nullptr;
+        if (hipGetSymbolAddress(&addr, HIP_SYMBOL(ln_static_scratch)) != hipSuccess || !addr) return MGX_ERR_LAUNCH;
+        p = (double*)addr;
+        __atomic_store_n(&g_ln_scratch[dev], p, __ATOMIC_RELEASE);   // racing first calls resolve the same address
+    }
+    *out = p;
+    return MGX_OK;
+}
+}  // namespace
+
+extern "C" int64_t mgx_layernorm_fwd_static_max_samples(void) { return kLnStaticPairs; }
+
+extern "C" int mgx_layernorm_fwd_static(const float* x, const float* gamma, const float* beta, float* y, float* stats,
+                                        int64_t nimg, int64_t e, float eps, void* stream) {
+    if (!x || !gamma || !beta || !y || !stats || nimg <= 0 || e <= 0) return MGX_ERR_ARG;
+    if (nimg > kLnStaticPairs) return MGX_ERR_WORKSPACE;        // more samples than the static scratch has pairs for
+    const long bps = ln_blocks_per_sample(nimg, e);
+    if (nimg * bps > kLnStaticPairs) return MGX_ERR_WORKSPACE;
+    double* part = nullptr;
+    const int rc = ln_static_address(&part);
+    if (rc != MGX_OK) return rc;
+    hipStream_t st = (hipStream_t)stream;
+    // every pair the second kernel reads is written by the first one of the same call: nothing to clear
+    hipLaunchKernelGGL(ln_partial_kernel, dim3((unsigned)bps, (unsigned)nimg), dim3(kBlock), 0, st, x, part, (long)e, bps);
+    hipLaunchKernelGGL(ln_stats_kernel, dim3((unsigned)nimg), dim3(64), 0, st, part, stats, (long)e, bps, eps);
+    long gx = (e / 2 + kBlock - 1) / kBlock;
+    const long cap = 4096 / nimg > 0 ? 4096 / nimg : 1;
+    if (gx > cap) gx = cap;
+    if (gx < 1) gx = 1;
+    hipLaunchKernelGGL(ln_apply_kernel, dim3((unsigned)gx, (unsigned)nimg), dim3(kBlock), 0, st, x, gamma, beta, stats, y,
+                       (long)e);
+    return mgx_launch_status();
+}
+
 extern "C" int mgx_layernorm_bwd(const float* dy, const float* x, const float* gamma, const float* stats, float* dx,
                                  int acc_x, float* dgamma, float* dbeta, int64_t nimg, int64_t e, void* workspace,
                                  int64_t workspace_bytes, void* stream) {
