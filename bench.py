@@ -1,22 +1,33 @@
 #!/usr/bin/env python3
 """Benchmark of the G+D training step (trainer/models.py:72-158) on MI355X.
 
-    python bench.py --gpus N --steps K --warmup W            (N = 1: run directly;
-    N > 1: launched by torch.distributed.run, one rank per GPU, data parallel over RCCL)
+    python bench.py --gpus N --steps K --warmup W
 
-A "step" is one WGAN.train_step over one batch of synthetic audio that is already resident in
-HBM.  Default workload (N = 1): BASELINE.json configs[1] — mid-stage fade-in step, stage 3
-(32 x 6000), batch 64 per GPU, fp32.  With N GPUs the global batch is 64*N (weak scaling).
+N = 1 runs in this process.  N > 1 without WORLD_SIZE in the environment starts its own N ranks
+(`python -m torch.distributed.run`, one per GPU, RCCL) before anything touches the GPU and relays
+rank 0's line; under an external torch.distributed.run it is a rank itself.
+
+A "step" is one WGAN.train_step over one batch of synthetic audio that is already resident in HBM.
+Timed workload (`value`): BASELINE.json configs[1] — mid-stage fade-in step, stage 3 (32 x 6000),
+batch 64 per GPU, fp32; with N GPUs the global batch is 64*N (weak scaling, batch sharded by
+MinibatchStdDev groups, gradient all-reduce over RCCL).
 
 Rank 0 prints ONE JSON line with, beside the contract fields,
-  roofline      the dominant kernel of the timed region: algorithmic FLOPs / launch duration,
-                measured with HIP events on the launch stream, against the dense f32 MFMA peak;
-  cpu_baseline  the CPU oracle's train step (float32, PyTorch-CPU) on a bounded sample of the
-                same workload, on this host's cores (N = 1 only).
+  roofline         the dominant kernel of the timed region: algorithmic FLOPs / launch duration, measured
+                   with HIP events on the launch stream, against the dense MFMA peak of its dtype;
+  cpu_baseline     the CPU oracle's train step (float32, PyTorch-CPU) on a bounded sample of the same
+                   workload, on this host's cores (N = 1 only); cpu_baseline_c1: BASELINE configs[0]
+                   (stage 0, batch 16) on the CPU, whole batch;
+  per_stage        (N = 1) samples/s of the fade-in step at every progressive stage 0-6, fp32 and bf16;
+  c3               (N = 1) BASELINE configs[2]: the full-resolution stage (256 x 48000), batch 256 in
+                   micro-batches of one MinibatchStdDev group, bf16: one timed step after a warm-up on 8
+                   samples, with the roofline of its dominant kernel against the bf16 dense MFMA peak.
 """
 import argparse
 import json
 import os
+import socket
+import subprocess
 import sys
 import time
 
@@ -25,27 +36,79 @@ if ROOT not in sys.path:
     sys.path.insert(0, ROOT)
 
 F32_MFMA_PEAK_TFLOPS = 157.3      # dense f32 matrix peak of MI355X
+BF16_MFMA_PEAK_TFLOPS = 2500.0    # dense bf16 matrix peak (no sparsity)
 # train-step GFLOP per sample (6 G forwards-equivalents + 13 D), stages 0..6
 STEP_GFLOP_PER_SAMPLE = [13.6, 59.9, 245.0, 985.0, 3947.0, 15794.0, 63182.0]
+# (batch, micro-batch) of the per-stage table: large batches at low resolution, memory-bounded above
+STAGE_PLAN = {0: (256, None), 1: (256, None), 2: (128, None), 3: (64, None), 4: (32, 16), 5: (16, 4), 6: (4, 4)}
 
 
-def cpu_baseline(stage, fade, sample_batch, n_blocks):
-    """Time the oracle's train step on the host (the reference's TensorFlow CPU path cannot run
-    here: TensorFlow/Keras are not installed)."""
-    import numpy as np
+def parse_args():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=3)
+    ap.add_argument("--warmup", type=int, default=1)
+    ap.add_argument("--stage", type=int, default=3)
+    ap.add_argument("--batch", type=int, default=64, help="per-GPU batch")
+    ap.add_argument("--straight", action="store_true", help="straight-through twin instead of fade-in")
+    ap.add_argument("--precision", default="float32", choices=["float32", "bfloat16"],
+                    help="bfloat16: 32/128-channel discriminator activations and the generator blocks on bf16 MFMAs "
+                         "with f32 accumulation")
+    ap.add_argument("--micro-batch", type=int, default=0, help="samples per micro-batch (multiple of 4; 0 = whole batch)")
+    ap.add_argument("--side-budget-gib", type=float, default=0.0,
+                    help="bound of the generator block's tape in GiB (re-computes above it; 0 = unbounded)")
+    ap.add_argument("--kernels", action="store_true", help="also print the per-kernel time table of the timed steps")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extras", action="store_true", help="skip per_stage and c3 (N = 1 extras)")
+    ap.add_argument("--reuse-real-logits", action="store_true",
+                    help="evaluate discriminator(real) once after the D update instead of three times (same values)")
+    ap.add_argument("--cpu-sample-batch", type=int, default=2)
+    ap.add_argument("--c3-batch", type=int, default=256)
+    ap.add_argument("--graph", action="store_true",
+                    help="replay the step as one HIP graph (WGAN.use_graph): for small batches, where the host's "
+                         "launch rate bounds the step; no per-kernel roofline in this mode")
+    ap.add_argument("--host-input", action="store_true",
+                    help="hand every step a host (numpy) batch, so the host-to-device copy is inside the timed "
+                         "region: the PCIe-inclusive rate, not the headline value")
+    return ap.parse_args()
+
+
+def self_launch(args):
+    """`python bench.py --gpus N` with N > 1 and no launcher: start N ranks as a child
+    torch.distributed.run (this process has not touched the GPU) and exit with its status."""
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", "--nproc-per-node", str(args.gpus),
+           "--master-addr", "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__)] + sys.argv[1:]
+    env = dict(os.environ)
+    env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
+    return subprocess.call(cmd, env=env)
+
+
+def cpu_baseline(stage, fade, sample_batch, n_blocks, timed=3):
+    """Median of `timed` oracle train steps after one warm-up, on the host (the reference's TensorFlow CPU
+    path cannot run here: TensorFlow/Keras are not installed)."""
     import torch
     from oracle import ref_step as R
-    cores = min(16, os.cpu_count() or 1)
+    cores = min(16, os.cpu_count() or 1)          # a one-GPU box grants 16 cores of the host
     torch.set_num_threads(cores)
     W = R.synthetic_weights(n_blocks, seed=100)
     real, z4 = R.synthetic_inputs(stage, sample_batch, seed=0)
-    t0 = time.time()
-    R.train_step(W, n_blocks, stage, fade, real, z4, alpha=0.5 if fade else None, dtype=torch.float32,
-                 keep_grads=False)
-    dt = time.time() - t0
-    return {"value": sample_batch / dt, "unit": "samples/s", "cores": cores, "kind": "port",
-            "sample": "one oracle train step (float32, PyTorch-CPU) of the same stage-%d %s workload at batch %d, %.1f s"
-                      % (stage, "fade-in" if fade else "straight", sample_batch, dt)}
+    times = []
+    for i in range(timed + 1):
+        t0 = time.time()
+        R.train_step(W, n_blocks, stage, fade, real, z4, alpha=0.5 if fade else None, dtype=torch.float32,
+                     keep_grads=False)
+        if i:
+            times.append(time.time() - t0)
+    dt = sorted(times)[len(times) // 2]
+    return {"value": round(sample_batch / dt, 4), "unit": "samples/s", "cores": cores,
+            "host_cpu_count": os.cpu_count(), "kind": "port",
+            "sample": "oracle train step (float32, PyTorch-CPU) of the stage-%d %s workload at batch %d: 1 warm-up, "
+                      "median of %d steps, %.2f s each" % (stage, "fade-in" if fade else "straight", sample_batch,
+                                                          timed, dt)}
 
 
 def measured_traffic(kernel, stage, fade, batch):
@@ -62,35 +125,122 @@ def measured_traffic(kernel, stage, fade, batch):
     entry = wl.get(kernel)
     if entry:
         return entry["hbm_bytes_per_launch"]
-    # a key without template arguments stands for all instantiations of the kernel: launch-weighted mean
     inst = [e for k, e in wl.items() if isinstance(e, dict) and k.startswith(kernel + "<")]
     n = sum(e["launches_per_step"] for e in inst)
     return round(sum(e["hbm_bytes_per_launch"] * e["launches_per_step"] for e in inst) / n) if n else None
 
 
+def build_gan(M, stage, fade, precision, micro_batch=None, side_budget_gib=0.0):
+    from music_generator_amd.graph import FusedGroup
+    M.backend.set_precision(precision)
+    M.clear_session()
+    d = M.define_discriminator(stage + 1)
+    g = M.define_generator(stage + 1)
+    gan = M.define_composite(d, g, (1, 100, 2))[stage][1 if fade else 0]
+    gan.micro_batch = micro_batch or None
+    FusedGroup.side_budget_bytes = int(side_budget_gib * 2 ** 30) if side_budget_gib else None
+    gan.set_train_steps(100)
+    return gan
+
+
+def roofline_of(summ, steps, ms_per_step, peak, traffic=None):
+    contr = {k: v for k, v in summ.items() if v[2] > 0.0}
+    key, (launches, ms, flops, nbytes) = max(contr.items(), key=lambda kv: kv[1][1])
+    achieved = flops / (ms * 1e-3) / 1e12
+    return key, {"bound": "mfma", "kernel": key, "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
+                 "frac": round(achieved / peak, 4), "traffic": traffic,
+                 "algorithmic_gflop_per_launch": round(flops / launches / 1e9, 2),
+                 "algorithmic_bytes_per_launch": round(nbytes / launches),
+                 "algorithmic_GBps": round(nbytes / ms / 1e6, 1),
+                 "launches": launches, "avg_launch_ms": round(ms / launches, 4),
+                 "share_of_step_time": round(ms / steps / ms_per_step, 3),
+                 "all_contractions_share_of_step_time": round(sum(v[1] for v in contr.values()) / steps / ms_per_step, 3)}
+
+
+def progress(msg):
+    """One line on stderr: long phases stay visibly alive for whoever watches the run."""
+    print("[bench %6.1f s] %s" % (time.perf_counter() - T_START, msg), file=sys.stderr, flush=True)
+
+
+T_START = time.perf_counter()
+
+
+def per_stage_table(torch, M):
+    """2 timed fade-in steps (after one warm-up) per stage and precision on one GPU."""
+    out = []
+    for stage in range(7):
+        batch, mb = STAGE_PLAN[stage]
+        row = {"stage": stage, "hw": [4 << stage, 750 << stage], "batch": batch, "micro_batch": mb}
+        for precision in ("float32", "bfloat16"):
+            torch.cuda.empty_cache()
+            gan = build_gan(M, stage, stage > 0, precision, mb, 8.0 if stage == 6 else 0.0)
+            real = torch.rand((batch, 4 << stage, 750 << stage, 2), device="cuda") * 2 - 1
+            gan.train_step(real)
+            torch.cuda.synchronize()
+            t0 = time.perf_counter()
+            for _ in range(2):
+                gan.train_step(real)
+            torch.cuda.synchronize()
+            dt = (time.perf_counter() - t0) / 2
+            tag = "f32" if precision == "float32" else "bf16"
+            row["samples_per_s_" + tag] = round(batch / dt, 2)
+            row["tflops_algorithmic_" + tag] = round(STEP_GFLOP_PER_SAMPLE[stage] * batch / dt / 1e3, 1)
+            progress("stage %d %s: %.1f samples/s" % (stage, tag, batch / dt))
+            del gan, real
+        out.append(row)
+    return out
+
+
+def c3_run(torch, M, ops, batch):
+    """BASELINE configs[2]: stage 6 (256 x 48000), batch `batch`, bf16, micro-batches of one MinibatchStdDev
+    group (4 samples), generator tape bounded to 8 GiB (re-computing backward).  Warm-up: one step on 8
+    samples (same micro-batch shapes); then ONE timed step on the whole batch."""
+    stage = 6
+    torch.cuda.empty_cache()
+    gan = build_gan(M, stage, True, "bfloat16", 4, 8.0)
+    gen = torch.Generator(device="cuda")
+    gen.manual_seed(7)
+    real = torch.rand((batch, 256, 48000, 2), device="cuda", generator=gen).mul_(2.0).sub_(1.0)
+    progress("c3: batch of %d clips resident, warm-up step on 8 samples" % batch)
+    gan.train_step(real[:8])
+    torch.cuda.synchronize()
+    torch.cuda.reset_peak_memory_stats()
+    progress("c3: timed step on %d samples (about a minute)" % batch)
+    prof = ops.LaunchProfiler()
+    ops.PROFILER = prof
+    t0 = time.perf_counter()
+    metrics = gan.train_step(real)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    ops.PROFILER = None
+    progress("c3: %.1f s per step, %.2f samples/s" % (dt, batch / dt))
+    summ = prof.summary()
+    _, roof = roofline_of(summ, 1, dt * 1e3, BF16_MFMA_PEAK_TFLOPS)
+    top = sorted(summ.items(), key=lambda kv: -kv[1][1])[:8]
+    out = {"workload": "stage-6 (256x48000) fade-in G+D train step, batch %d (micro-batches of 4), bf16 storage / "
+                       "bf16 MFMA / f32 accumulation, f32 master weights" % batch,
+           "value": round(batch / dt, 3), "unit": "samples/s", "steps": 1, "warmup": "1 step on 8 samples",
+           "ms_per_step": round(dt * 1e3, 1), "dtype": "bf16",
+           "step_tflops_algorithmic": round(STEP_GFLOP_PER_SAMPLE[stage] * batch / dt / 1e3, 1),
+           "frac_of_bf16_mfma_peak": round(STEP_GFLOP_PER_SAMPLE[stage] * batch / dt / 1e3 / BF16_MFMA_PEAK_TFLOPS, 4),
+           "peak_hbm_gib": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1),
+           "roofline": roof,
+           "top_kernels": {k: {"ms": round(v[1], 1), "TFLOP/s": round(v[2] / v[1] / 1e9, 1),
+                               "GB/s": round(v[3] / v[1] / 1e6, 1)} for k, v in top},
+           "last_metrics": {k: float(v) for k, v in metrics.items()}}
+    del gan, real
+    torch.cuda.empty_cache()
+    M.backend.set_precision("float32")
+    return out
+
+
 def main():
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=3)
-    ap.add_argument("--warmup", type=int, default=1)
-    ap.add_argument("--stage", type=int, default=3)
-    ap.add_argument("--batch", type=int, default=64, help="per-GPU batch")
-    ap.add_argument("--straight", action="store_true", help="straight-through twin instead of fade-in")
-    ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--reuse-real-logits", action="store_true",
-                    help="evaluate discriminator(real) once after the D update instead of three times (same values)")
-    ap.add_argument("--cpu-sample-batch", type=int, default=2)
-    ap.add_argument("--graph", action="store_true",
-                    help="replay the step as one HIP graph (WGAN.use_graph): for small batches, where the host's "
-                         "launch rate bounds the step; no per-kernel roofline in this mode")
-    ap.add_argument("--precision", default="float32", choices=["float32", "bfloat16"],
-                    help="bfloat16: 32/128-channel discriminator activations stored as bf16, bf16 MFMA, f32 accumulation")
-    ap.add_argument("--micro-batch", type=int, default=0, help="samples per micro-batch (multiple of 4; 0 = whole batch)")
-    ap.add_argument("--kernels", action="store_true", help="also print the per-kernel time table of the timed steps")
-    ap.add_argument("--host-input", action="store_true",
-                    help="hand every step a host (numpy) batch, so the host-to-device copy is inside the timed "
-                         "region: the PCIe-inclusive rate, not the headline value")
-    args = ap.parse_args()
+    args = parse_args()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(self_launch(args))
+    rank = int(os.environ.get("RANK", "0"))
+    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
 
     import numpy as np
     import torch
@@ -98,31 +248,17 @@ def main():
     from music_generator_amd import ops
     from music_generator_amd.parallel import DataParallel
 
-    world = int(os.environ.get("WORLD_SIZE", "1"))
-    rank = int(os.environ.get("RANK", "0"))
-    local_rank = int(os.environ.get("LOCAL_RANK", "0"))
-    if world != args.gpus:
-        if world == 1 and args.gpus > 1:
-            raise SystemExit("launch with: python -m torch.distributed.run --nproc-per-node %d bench.py --gpus %d ..."
-                             % (args.gpus, args.gpus))
     # one rank per GPU; MGX_BENCH_BACKEND=gloo rehearses the multi-rank flow on a box with fewer GPUs
     # than ranks (RCCL refuses two ranks on one device)
     backend = os.environ.get("MGX_BENCH_BACKEND", "nccl")
     torch.cuda.set_device(local_rank % torch.cuda.device_count() if backend != "nccl" else local_rank)
     dist = DataParallel(backend=backend) if world > 1 else None
 
-    M.backend.set_precision(args.precision)
     stage, fade = args.stage, (not args.straight and args.stage > 0)
     n_blocks = stage + 1
-    M.clear_session()
-    d = M.define_discriminator(n_blocks)
-    g = M.define_generator(n_blocks)
-    comp = M.define_composite(d, g, (1, 100, 2))
-    gan = comp[stage][1 if fade else 0]
+    gan = build_gan(M, stage, fade, args.precision, args.micro_batch, args.side_budget_gib)
     gan.dist = dist
     gan.reuse_real_logits = args.reuse_real_logits
-    if args.micro_batch:
-        gan.micro_batch = args.micro_batch
     if args.graph:
         if world > 1:
             raise SystemExit("--graph is a single-GPU mode")
@@ -130,13 +266,11 @@ def main():
         args.warmup = max(args.warmup, 2)        # eager step, then the capturing step
     if dist is not None:
         dist.broadcast_weights(gan.discriminator, gan.generator)
-    gan.set_train_steps(100)
     gan.seed(1234 + rank)
     h, w = 4 << stage, 750 << stage
     gen = torch.Generator(device="cuda")
     gen.manual_seed(99 + rank)
     real = torch.rand((args.batch, h, w, 2), device="cuda", generator=gen) * 2.0 - 1.0   # synthetic audio in HBM
-
     if args.host_input:
         real = real.cpu().numpy()
 
@@ -156,68 +290,68 @@ def main():
     sync()
     elapsed = time.perf_counter() - t0
     ops.PROFILER = None
+    backend_name = torch.distributed.get_backend() if dist is not None else None
     if dist is not None:
         t = torch.tensor([elapsed], device="cuda" if backend == "nccl" else "cpu", dtype=torch.float64)
         torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
         elapsed = float(t.item())
     last = {k: float(v) for k, v in metrics.items()}
+    ranks = torch.distributed.get_world_size() if dist is not None else 1
     if dist is not None:
         torch.distributed.destroy_process_group()
     if not all(np.isfinite(list(last.values()))):
         raise SystemExit("non-finite metrics: %r" % (last,))
-
     if rank != 0:
         return
+
     ms_per_step = elapsed / args.steps * 1e3
+    progress("timed region: %.1f ms per step" % ms_per_step)
     global_batch = args.batch * world
     value = global_batch * args.steps / elapsed
-    if prof is None:
-        print(json.dumps({"metric": "G+D train-step samples/sec", "value": round(value, 3), "unit": "samples/s",
-                          "n_gpus": 1, "steps": args.steps, "warmup": args.warmup,
-                          "ms_per_step": round(ms_per_step, 3), "higher_is_better": True, "scaling": "weak",
-                          "vs_baseline": None, "dtype": "f32", "data": "synthetic",
-                          "config": {"workload": "stage-%d (%dx%d) %s G+D train step, batch %d, fp32, HIP graph replay"
-                                                 % (stage, h, w, "fade-in" if fade else "straight-through", args.batch)},
-                          "step_tflops_algorithmic": round(STEP_GFLOP_PER_SAMPLE[stage] * args.batch / ms_per_step, 2),
-                          "last_metrics": last}))
-        return
-    summ = prof.summary()
-    if args.kernels:
-        for k, v in sorted(summ.items(), key=lambda kv: -kv[1][1]):
-            print("%-40s n=%5d  %9.2f ms  %7.1f TFLOP/s  %7.1f GB/s" % (k, v[0], v[1], v[2] / max(v[1], 1e-9) / 1e9,
-                                                                      v[3] / max(v[1], 1e-9) / 1e6), file=sys.stderr)
-    # bandwidth-bound kernels (zero FLOPs recorded): achieved GB/s against the 8 TB/s HBM peak
-    hbm_ops = {k: {"launches": v[0], "ms": round(v[1], 3), "GB/s": round(v[3] / v[1] / 1e6, 1),
-                   "frac_of_8TBps": round(v[3] / v[1] / 1e6 / 8000.0, 3)}
-               for k, v in summ.items() if v[2] == 0.0 and v[1] > 0}
-    summ = {k: v for k, v in summ.items() if v[2] > 0.0}
-    key, (launches, ms, flops, nbytes) = max(summ.items(), key=lambda kv: kv[1][1])
-    achieved = flops / (ms * 1e-3) / 1e12
-    contraction_ms = sum(v[1] for v in summ.values())
-    roofline = {"bound": "mfma", "kernel": key, "achieved": round(achieved, 2), "peak": F32_MFMA_PEAK_TFLOPS,
-                "unit": "TFLOP/s", "frac": round(achieved / F32_MFMA_PEAK_TFLOPS, 4),
-                "traffic": measured_traffic(key, stage, fade, args.batch),
-                "algorithmic_gflop_per_launch": round(flops / launches / 1e9, 2),
-                "algorithmic_bytes_per_launch": round(nbytes / launches),
-                "launches": launches, "avg_launch_ms": round(ms / launches, 4),
-                "share_of_step_time": round(ms / args.steps / ms_per_step, 3),
-                "all_contractions_share_of_step_time": round(contraction_ms / args.steps / ms_per_step, 3),
-                "step_tflops_algorithmic": round(STEP_GFLOP_PER_SAMPLE[stage] * args.batch / ms_per_step, 2)}
-    if key.startswith("wino3_"):
-        # the kernel's algorithm is Winograd F(2x2,3x3): `achieved` counts the multiply-adds it executes
-        # (16 per 2x2 patch and channel pair); the same launches as a rate of direct-convolution FLOPs:
-        roofline["direct_convolution_equivalent_tflops"] = round(achieved / ops.WINOGRAD_FLOP_FRACTION, 2)
+    dtype = "f32" if args.precision == "float32" else "bf16"
+    pname = "fp32" if args.precision == "float32" else "bf16 storage + bf16 MFMA, f32 accumulation"
     out = {"metric": "G+D train-step samples/sec", "value": round(value, 3), "unit": "samples/s", "n_gpus": world,
            "steps": args.steps, "warmup": args.warmup, "ms_per_step": round(ms_per_step, 3),
-           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": "f32",
+           "higher_is_better": True, "scaling": "weak", "vs_baseline": None, "dtype": dtype,
            "data": "synthetic (host-resident batch, copied to HBM inside every step)" if args.host_input else "synthetic",
-           "config": {"workload": "stage-%d (%dx%d) %s G+D train step, batch %d per GPU, fp32"
-                                  % (stage, h, w, "fade-in" if fade else "straight-through", args.batch),
+           "config": {"workload": "stage-%d (%dx%d) %s G+D train step, batch %d per GPU, %s%s"
+                                  % (stage, h, w, "fade-in" if fade else "straight-through", args.batch, pname,
+                                     ", HIP graph replay" if args.graph else ""),
                       "global_batch": global_batch, "parallelism": "dp%d" % world,
                       "discriminator_real_passes_per_step": 2 if args.reuse_real_logits else 4},
-           "roofline": roofline, "hbm_ops": hbm_ops, "last_metrics": last}
-    if world == 1 and not args.no_cpu_baseline:
-        out["cpu_baseline"] = cpu_baseline(stage, fade, args.cpu_sample_batch, n_blocks)
+           "step_tflops_algorithmic": round(STEP_GFLOP_PER_SAMPLE[stage] * args.batch / ms_per_step, 2),
+           "last_metrics": last}
+    if world > 1:
+        out["rccl_ranks"] = ranks
+        out["collective_backend"] = backend_name
+    if prof is not None:
+        summ = prof.summary()
+        if args.kernels:
+            for k, v in sorted(summ.items(), key=lambda kv: -kv[1][1]):
+                print("%-40s n=%5d  %9.2f ms  %7.1f TFLOP/s  %7.1f GB/s" % (k, v[0], v[1], v[2] / max(v[1], 1e-9) / 1e9,
+                                                                          v[3] / max(v[1], 1e-9) / 1e6), file=sys.stderr)
+        # bandwidth-bound kernels (zero FLOPs recorded): achieved GB/s against the 8 TB/s HBM peak
+        out["hbm_ops"] = {k: {"launches": v[0], "ms": round(v[1], 3), "GB/s": round(v[3] / v[1] / 1e6, 1),
+                              "frac_of_8TBps": round(v[3] / v[1] / 1e6 / 8000.0, 3)}
+                          for k, v in summ.items() if v[2] == 0.0 and v[1] > 0}
+        key, roof = roofline_of(summ, args.steps, ms_per_step,
+                                BF16_MFMA_PEAK_TFLOPS if args.precision == "bfloat16" else F32_MFMA_PEAK_TFLOPS)
+        roof["traffic"] = measured_traffic(key, stage, fade, args.batch)
+        if key.startswith("wino3_"):
+            # the kernel's algorithm is Winograd F(2x2,3x3): `achieved` counts the multiply-adds it executes
+            # (16 per 2x2 patch and channel pair); the same launches as a rate of direct-convolution FLOPs:
+            roof["direct_convolution_equivalent_tflops"] = round(roof["achieved"] / ops.WINOGRAD_FLOP_FRACTION, 2)
+        out["roofline"] = roof
+    if world == 1 and not args.graph:
+        del gan, real
+        if not args.no_extras:
+            out["per_stage"] = per_stage_table(torch, M)
+            out["c3"] = c3_run(torch, M, ops, args.c3_batch)
+        if not args.no_cpu_baseline:
+            progress("CPU baseline")
+            out["cpu_baseline"] = cpu_baseline(stage, fade, args.cpu_sample_batch, n_blocks)
+            out["cpu_baseline_c1"] = cpu_baseline(0, False, 16, 1, timed=5)
+            progress("done")
     print(json.dumps(out))
 
 

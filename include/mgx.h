@@ -243,7 +243,8 @@ int mgx_wgan_loss(const float* sums, int64_t n_global, int mode, float* out4,
 /* out = ca[0]*a + cb[0]*b (b, cb may be NULL): the loss gradients dloss/dlogit are uniform over the
  * batch (see mgx_wgan_loss), so the step back-propagates unit seeds per micro-batch, separately for
  * the fake and the real pass, and scales / combines the two flat gradient buffers here once the
- * batch-wide sign is known.  ca, cb are device scalars (dfake[0], dreal[0] of mgx_wgan_loss). */
+ * batch-wide sign is known.  ca, cb are device scalars (dfake[0], dreal[0] of mgx_wgan_loss).  out may
+ * be the same buffer as a. */
 int mgx_combine_grads(float* out, const float* a, const float* b, const float* ca, const float* cb, int64_t n,
                       void* stream);
 

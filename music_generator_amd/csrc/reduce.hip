@@ -295,8 +295,9 @@ __global__ __launch_bounds__(kBlock) void logit_sums_kernel(const float* __restr
     }
 }
 
-// out = ca[0]*a + cb[0]*b (b optional): combines gradients taken with unit logit seeds
-__global__ __launch_bounds__(kBlock) void combine_kernel(float* __restrict__ out, const float* __restrict__ a,
+// out = ca[0]*a + cb[0]*b (b optional): combines gradients taken with unit logit seeds.  out may be
+// the same buffer as a (the step scales in place), so neither carries a no-alias promise.
+__global__ __launch_bounds__(kBlock) void combine_kernel(float* out, const float* a,
                                                          const float* __restrict__ b, const float* __restrict__ ca,
                                                          const float* __restrict__ cb, long n) {
     const float fa = ca[0], fb = b ? cb[0] : 0.f;

@@ -312,8 +312,7 @@ def _register_fused_block(block_end, upsampling, for_sum_layer):
         side = ops.gblock_side_floats(n * hl * wl)
         budget = FusedGroup.side_budget_bytes
         if budget is not None and 4 * side > budget:
-            ops.gblock_fwd(w, state["pack"], x, y, n, hl, wl)
-            return y, (None, x, (n, hl, wl))
+            return run(x), (None, x, (n, hl, wl))
         act = K.empty((side,))
         ops.gblock_fwd(w, state["pack"], x, y, n, hl, wl, act=act)
         return y, (act, None, (n, hl, wl))
@@ -711,7 +710,7 @@ class WGAN:
             flat_r = D.bind_grads(1)
             flat_r.zero_()
             sums = K.zeros((2,))
-            pending = None
+            pending = pending_r = None
             for bi, idx in enumerate(batches):
                 zb, rb = self._take(z, idx), self._take(real, idx)
                 ones = self._ones(rb.shape[0])
@@ -729,11 +728,14 @@ class WGAN:
                 D.bind_grads(1)
                 D.backward(tape, ones, need_input_grad=False)
                 del tape
+                if self.dist is not None and bi == len(batches) - 1:
+                    # the real-pass sums are final too: reduced beside the logit sums / loss kernel below
+                    pending_r = self.dist.all_reduce_async(flat_r)
                 ops.logit_sums(fake_logits.view(-1), real_logits.view(-1), sums, accumulate=True)
             out_d, cf, cr = self._finish_sums(sums, 0, n, True)
             if self.dist is not None:
-                self.dist.all_reduce(flat_r)
                 self.dist.wait_for(pending)
+                self.dist.wait_for(pending_r)
             ops.combine_grads(flat_f, flat_f, flat_r, cf, cr)
             D.bind_grads(0)
             self.d_optimizer.apply_model_gradients(D, None if scal is None else scal[1:2])
@@ -752,7 +754,8 @@ class WGAN:
         flat_g = G.bind_grads(0)
         flat_g.zero_()
         sums = K.zeros((2,))
-        for idx in batches:
+        pending_g = None
+        for bi, idx in enumerate(batches):
             zb, rb = self._take(z, idx), self._take(real, idx)
             nb = zb.shape[0]
             chunk = self.generator_chunk if (self.generator_chunk and self.generator_chunk < nb) else None
@@ -772,14 +775,19 @@ class WGAN:
                     _, tape_g = G.forward(zb[s0:s0 + chunk], save=True)
                     G.backward(tape_g, dgen[s0:s0 + chunk], need_input_grad=False)
             del tape_g, dgen
+            if self.dist is not None and bi == len(batches) - 1:
+                # the unit-seed generator gradients are final: their all-reduce (the largest message of the
+                # step) runs beside the discriminator forward on the real batch below; scaling by the loss
+                # coefficient afterwards is the same linear map on every rank
+                pending_g = self.dist.all_reduce_async(flat_g)
             real_logits = D(rb).view(-1) if real_sum is None else None
             ops.logit_sums(gen_logits.view(-1), real_logits, sums, accumulate=True)
         if real_sum is not None:
             sums[1:2].copy_(real_sum)
         out_g, cf, _ = self._finish_sums(sums, 1, n, True)
-        ops.combine_grads(flat_g, flat_g, None, cf, None)
         if self.dist is not None:
-            self.dist.all_reduce(flat_g)
+            self.dist.wait_for(pending_g)
+        ops.combine_grads(flat_g, flat_g, None, cf, None)
         self.g_optimizer.apply_model_gradients(G, None if scal is None else scal[2:3])
 
         # ---- metric block 1 ----

@@ -460,3 +460,23 @@ def test_graph_replayed_step_equals_eager_step(stage, fade):
     assert m_e == m_g
     for a, b in zip(w_e, w_g):
         assert np.array_equal(a, b)
+
+
+def test_bench_starts_its_own_ranks():
+    """`python bench.py --gpus 2` without a launcher starts two ranks itself (torch.distributed.run as a
+    child, before the parent touches the GPU) and relays rank 0's line.  RCCL refuses two ranks on one
+    device, so the rehearsal on this one-GPU box carries the collectives over gloo."""
+    import json
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    env = dict(os.environ, MGX_BENCH_BACKEND="gloo")
+    env.pop("WORLD_SIZE", None)
+    res = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--stage", "1", "--batch", "8",
+                          "--steps", "2", "--warmup", "1"], env=env, capture_output=True, text=True, timeout=280)
+    assert res.returncode == 0, res.stderr[-2000:]
+    lines = [l for l in res.stdout.splitlines() if l.startswith("{")]
+    assert len(lines) == 1, res.stdout[-2000:]
+    out = json.loads(lines[0])
+    assert out["n_gpus"] == 2 and out["rccl_ranks"] == 2 and out["collective_backend"] == "gloo"
+    assert out["config"]["global_batch"] == 16 and out["value"] > 0
