@@ -317,14 +317,23 @@ int mgx_weighted_sum_bf16_fwd(const void* a, const void* b, const float* alpha, 
 int mgx_weighted_sum_bf16_bwd(const void* dy, const void* a, const void* b, const float* alpha, void* da, void* db,
                               float* dalpha, void* workspace, int64_t workspace_bytes, int64_t n, void* stream);
 
-/* The generator grow block of mgx_gblock_fwd_f32 (add_generator_block, models.py:362-399) on bf16 MFMAs with
- * float32 accumulation, for forwards that keep no tape (models.py:110, 125, 151; utils.py:81, 104): x
- * (nimg, hl, wl, 2) and y (nimg, 2*hl, 2*wl, 2) float32, weights float32 (Keras layout); every
- * intermediate activation is rounded to bf16 in registers.  `packb` is scratch of
- * mgx_gblock_pack_bf16_bytes() bytes that the call refills from the weights. */
+/* The generator grow block of mgx_gblock_fwd_f32 / _dgrad_f32 / _wgrad_f32 (add_generator_block,
+ * models.py:362-399, and its part of tape.gradient, models.py:144-146) on bf16 MFMAs with float32
+ * accumulation.  x, y, dy, dx (2 channels) and all weights / weight gradients are float32; every
+ * intermediate activation and gradient is rounded to bf16 once, in registers, and the side buffers (`act`,
+ * `delta`: mgx_gblock_side_elems_bf16(npos) bf16 elements each, same tile-major row map as the float32
+ * ones) hold bf16.  Position ranges, the scratch buffers `packb` / `packt` (mgx_gblock_pack_bf16_bytes /
+ * mgx_gblock_packt_bf16_bytes bytes, refilled by the call with pos0 = 0) and the weight-gradient workspace
+ * (mgx_gblock_wgrad_workspace_n bytes) work as in the float32 entry points. */
 int64_t mgx_gblock_pack_bf16_bytes(void);
-int mgx_gblock_fwd_bf16(const mgx_gblock_weights* w, void* packb, const float* x, float* y, int64_t nimg, int hl,
-                        int wl, void* stream);
+int64_t mgx_gblock_packt_bf16_bytes(void);
+int64_t mgx_gblock_side_elems_bf16(int64_t npos);
+int mgx_gblock_fwd_bf16(const mgx_gblock_weights* w, void* packb, const float* x, float* y, void* act, int64_t nimg,
+                        int hl, int wl, int64_t pos0, int64_t npos, void* stream);
+int mgx_gblock_dgrad_bf16(const mgx_gblock_weights* w, void* packt, const float* dy, void* delta, float* dx,
+                          int64_t nimg, int hl, int wl, int64_t pos0, int64_t npos, void* stream);
+int mgx_gblock_wgrad_bf16(const void* act, const void* delta, const mgx_gblock_grads* g, void* workspace,
+                          int64_t workspace_bytes, int64_t npos, void* stream);
 
 /* out = a (.) b over n elements (n a multiple of 8): b and out bf16, a bf16 or float32 (a_is_f32): the
  * product dY (.) f' of tf.GradientTape through a SoftRectifier (models.py:205-206) where the kernel that

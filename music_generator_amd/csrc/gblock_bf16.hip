@@ -17,6 +17,7 @@
 // persistent (one per CU) and walk tiles of 128 positions, so the stream never restarts.
 #include "bf16.h"
 #include "gblock_frag.h"
+#include "gblock_rows.h"
 #include "../../include/mgx.h"
 
 namespace {
@@ -130,6 +131,26 @@ __device__ __forceinline__ BTile to_b(const f32x16& a) {
     return t;
 }
 
+// Rows chan(8s + j, h) (s < NS k-steps) of a converted tile -> 32-position bf16 rows of a tile-major side
+// buffer (row map: gblock_rows.h).  Element pairs of a dword are two consecutive rows of one position.
+// the two bf16 halves of a dword -> rows `row` and `row + 1` of position r
+__device__ __forceinline__ void store_pair(bf16_t* __restrict__ buf, int row, int r, unsigned u) {
+    unsigned short* p = (unsigned short*)buf;
+    p[row * 32 + r] = (unsigned short)(u & 0xffffu);
+    p[(row + 1) * 32 + r] = (unsigned short)(u >> 16);
+}
+
+template <int NS>
+__device__ __forceinline__ void save_b(bf16_t* __restrict__ buf, int row0, const BTile& t, int r, int h) {
+#pragma unroll
+    for (int s = 0; s < NS; ++s)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+            const int row = row0 + chan(8 * s + 2 * q, h);
+            store_pair(buf, row, r, t.k[s][q]);
+        }
+}
+
 __device__ __forceinline__ u32x4 frag(const unsigned char* buf, int f, int lane) {
     return *(const u32x4*)(buf + f * 1024 + lane * 16);
 }
@@ -142,9 +163,11 @@ __device__ __forceinline__ void stage(const unsigned char* __restrict__ packb, i
                                          (__attribute__((address_space(3))) void*)(dst + f * 1024), 16, 0, 0);
 }
 
+template <bool SAVE>
 __global__ __launch_bounds__(256, 1) void gblock_fwd_bf16_kernel(const unsigned char* __restrict__ packb,
                                                                  const float* __restrict__ x, float* __restrict__ y,
-                                                                 long npix, int hl, int wl, long ntiles) {
+                                                                 bf16_t* __restrict__ act, long pos0, long npix, int hl,
+                                                                 int wl, long ntiles) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -164,13 +187,15 @@ __global__ __launch_bounds__(256, 1) void gblock_fwd_bf16_kernel(const unsigned 
     __syncthreads();
     int par = 0;                                             // buffer of the current phase
     for (; tile < ntiles; tile += gridDim.x) {
-        const long p = tile * 128 + wv * 32 + r;
+        const long p = pos0 + tile * 128 + wv * 32 + r;     // side-buffer tiles are counted from pos0
         const bool pvalid = p < npix;
         const long pc = pvalid ? p : 0;
+        // positions past the end contribute activations of a zero input; their gradients are zero
         const float2 xv = pvalid ? *(const float2*)(x + pc * 2) : make_float2(0.f, 0.f);
         const long row = pc / wl;
         const int jcol = (int)(pc - row * wl);
-        float* yrow0 = y + ((row * 2) * (2L * wl) + 2L * jcol) * 2;
+        float* yrow0 = y ? y + ((row * 2) * (2L * wl) + 2L * jcol) * 2 : nullptr;
+        bf16_t* at = SAVE ? act + (tile * 4 + wv) * (GB_ROWS * 32L) : nullptr;
         // B operand of the featured conv: element j = x[channel j & 1] for each of the 4 taps.  Only 8 of the
         // 16 contraction slots are needed, so the block input goes in as two bf16 parts, x = hi + lo (lane
         // half 0 carries hi, half 1 the remainder): the 2-channel input keeps 16 significant bits.
@@ -179,9 +204,13 @@ __global__ __launch_bounds__(256, 1) void gblock_fwd_bf16_kernel(const unsigned 
         const unsigned xp = h == 0 ? xhi : xlo;
         const u32x4 xb = (u32x4){xp, xp, xp, xp};
         const bool more_tiles = tile + gridDim.x < ntiles;
+        if (SAVE) {
+            at[(GB_X + 0) * 32 + r] = (bf16_t)xv.x;      // both lane halves write the same two values
+            at[(GB_X + 1) * 32 + r] = (bf16_t)xv.y;
+        }
 #pragma unroll 1
         for (int A = 0; A < 2; ++A) {
-            float* yrow = yrow0 + A * (2L * wl) * 2;
+            float* yrow = yrow0 ? yrow0 + A * (2L * wl) * 2 : nullptr;
             BTile Fb[4];
 #pragma unroll
             for (int it = 0; it < 4; ++it) {
@@ -189,6 +218,7 @@ __global__ __launch_bounds__(256, 1) void gblock_fwd_bf16_kernel(const unsigned 
                 init_bias(F, bias + BO_B0 + it * 32, h, 127, 4);
                 F = mfma_bf16(frag(fbuf, it, lane), xb, F);
                 Fb[it] = to_b(F);
+                if (SAVE && A == 0) save_b<2>(at, GB_F + it * 32, Fb[it], r, h);
             }
             f32x16 S[2][4];
 #pragma unroll
@@ -207,10 +237,13 @@ __global__ __launch_bounds__(256, 1) void gblock_fwd_bf16_kernel(const unsigned 
 #pragma unroll
                     for (int ks = 0; ks < 2; ++ks) o1 = mfma_bf16(frag(wb, FB_K1 + it * 2 + ks, lane), Fb[it].k[ks], o1);
                 const BTile o1b = to_b(o1);
+                bf16_t* abr = SAVE ? at + (GB_BR + k * GB_BR_ROWS) * 32 : nullptr;
+                if (SAVE && A == 0) save_b<2>(abr, GB_O1, o1b, r, h);
                 f32x16 o2;
                 init_bias(o2, bb + 16, h, 31, 4);
                 o2 = mfma_bf16(frag(wb, FB_D1, lane), A ? o1b.k[1] : o1b.k[0], o2);      // the 16 channels of sub-row A
                 const BTile o2b = to_b(o2);
+                if (SAVE) save_b<2>(abr, GB_O2 + A * 32, o2b, r, h);
 #pragma unroll
                 for (int b = 0; b < 2; ++b) {
                     BTile o3b[2];
@@ -222,6 +255,7 @@ __global__ __launch_bounds__(256, 1) void gblock_fwd_bf16_kernel(const unsigned 
                         for (int ks = 0; ks < 2; ++ks)
                             o3 = mfma_bf16(frag(wb, FB_K2 + (b * 2 + ot) * 2 + ks, lane), o2b.k[ks], o3);
                         o3b[ot] = to_b(o3);
+                        if (SAVE) save_b<2>(abr, GB_O3 + (A * 2 + b) * 64 + ot * 32, o3b[ot], r, h);
                     }
 #pragma unroll
                     for (int ot = 0; ot < 4; ++ot)
@@ -239,7 +273,10 @@ __global__ __launch_bounds__(256, 1) void gblock_fwd_bf16_kernel(const unsigned 
 #pragma unroll
             for (int b = 0; b < 2; ++b)
 #pragma unroll
-                for (int it = 0; it < 4; ++it) Sb[b][it] = to_b(S[b][it]);
+                for (int it = 0; it < 4; ++it) {
+                    Sb[b][it] = to_b(S[b][it]);
+                    if (SAVE) save_b<2>(at, GB_S + (A * 2 + b) * 128 + it * 32, Sb[b][it], r, h);
+                }
             f32x16 T2[2][2];
 #pragma unroll
             for (int b = 0; b < 2; ++b)
@@ -264,6 +301,7 @@ __global__ __launch_bounds__(256, 1) void gblock_fwd_bf16_kernel(const unsigned 
 #pragma unroll
                             for (int ks = 0; ks < 2; ++ks) T1 = mfma_bf16(frag(wc, it * 2 + ks, lane), Sb[b][it].k[ks], T1);
                         const BTile T1b = to_b(T1);
+                        if (SAVE) save_b<2>(at, GB_T1 + (A * 2 + b) * 256 + c * 32, T1b, r, h);
 #pragma unroll
                         for (int ot = 0; ot < 2; ++ot)
 #pragma unroll
@@ -276,6 +314,10 @@ __global__ __launch_bounds__(256, 1) void gblock_fwd_bf16_kernel(const unsigned 
 #pragma unroll
                     for (int b = 0; b < 2; ++b) {
                         const BTile t0 = to_b(T2[b][0]), t1 = to_b(T2[b][1]);
+                        if (SAVE) {
+                            save_b<2>(at, GB_T2 + (A * 2 + b) * 64, t0, r, h);
+                            save_b<2>(at, GB_T2 + (A * 2 + b) * 64 + 32, t1, r, h);
+                        }
                         f32x16 T3, O;
                         init_bias(T3, bias + BO_E3, h, 7, 1);
                         T3 = mfma_bf16(frag(w3, 0, lane), t0.k[0], T3);
@@ -283,10 +325,14 @@ __global__ __launch_bounds__(256, 1) void gblock_fwd_bf16_kernel(const unsigned 
                         T3 = mfma_bf16(frag(w3, 2, lane), t1.k[0], T3);
                         T3 = mfma_bf16(frag(w3, 3, lane), t1.k[1], T3);
                         const BTile t3 = to_b(T3);
+                        if (SAVE) {
+#pragma unroll
+                            for (int q = 0; q < 2; ++q) store_pair(at, GB_T3 + (A * 2 + b) * 8 + 4 * h + 2 * q, r, t3.k[0][q]);
+                        }
                         init_bias(O, bias + BO_E4, h, 7, 1);
                         O = mfma_bf16(frag(w3, 4, lane), t3.k[0], O);
                         // rows 0,1 (the two output channels) live in registers 0,1 of lane half 0
-                        if (pvalid && h == 0) *(float2*)(yrow + b * 2) = make_float2(O[0], O[1]);
+                        if (pvalid && h == 0 && yrow) *(float2*)(yrow + b * 2) = make_float2(O[0], O[1]);
                     }
                 }
                 __syncthreads();
@@ -296,26 +342,304 @@ __global__ __launch_bounds__(256, 1) void gblock_fwd_bf16_kernel(const unsigned 
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// Data-gradient chain dY -> dX of the block (the generator part of tape.gradient, models.py:144-146) on bf16
+// MFMAs: the mirror of the forward kernel with transposed weight fragments (A operand of step (ks, j) for
+// lane (i, h): W[input row i][output channel chan(8 ks + j, h)]).  Every intermediate gradient a weight
+// gradient needs goes to the bf16 gradient side buffer `delta` (row map: gblock_rows.h).  Phases per
+// sub-row a: two halves of the Dense tail (both sub-columns against the same staged weights), then the six
+// branches; fragments reach LDS by LDS-DMA one phase ahead, as in the forward kernel.
+// ------------------------------------------------------------------------------------------
+constexpr int PT_K0 = 0;                 // [it 4][ks 2]: rows >= 2 zero, the four taps summed
+constexpr int PT_TAIL = 8;               // W4T (1) | W3T [ot 2] | pad (1) | per chunk c: W2T [it 2][ks 2], W1T [ot 4][ks 2]
+constexpr int PT_TAIL_LO = 4 + 4 * TCH;  // 52 fragments: W4T, W3T, chunks 0-3
+constexpr int PT_TAIL_HI = 4 * TCH;      // 48 fragments: chunks 4-7
+constexpr int PT_BR = PT_TAIL + PT_TAIL_LO + PT_TAIL_HI;   // 108: 6 branches x 34
+constexpr int PBR = 34;
+constexpr int PB_D2 = 0;                 //   [it 2][ot 4][ks 2]
+constexpr int PB_K2 = 16;                //   [b 2][it 2][ks 2]
+constexpr int PB_D1 = 24;                //   [ks 2], rows >= 16 zero
+constexpr int PB_K1 = 26;                //   [a 2][ot 4]
+constexpr int NFT = PT_BR + 6 * PBR;     // 312
+constexpr int TBUF_BYTES = PT_TAIL_LO * 1024;
+constexpr int TLDS_BYTES = 8 * 1024 + 2 * TBUF_BYTES;
+
+__global__ __launch_bounds__(256) void gblock_packT_bf16_kernel(mgx_gblock_weights w, unsigned char* __restrict__ packt) {
+    const int idx = blockIdx.x * 256 + threadIdx.x;
+    if (idx >= NFT * 512) return;
+    const int f = idx >> 9, lane = (idx >> 3) & 63, j = idx & 7;
+    const int i = lane & 31, h = lane >> 5;
+    float v = 0.f;
+    if (f < PT_TAIL) {                                   // K0 (2,2,2,128): [tap][c][n]
+        const int it = f >> 1, ks = f & 1;
+        if (i < 2)
+            for (int tap = 0; tap < 4; ++tap) v += w.k0[(tap * 2 + i) * 128 + 32 * it + chan(8 * ks + j, h)];
+    } else if (f < PT_BR) {
+        const int g = f - PT_TAIL;
+        if (g == 0) {                                    // W4 (8,2): slot (h, j<2) = output channel j (dY as hi + lo parts)
+            v = (i < 8 && j < 2) ? w.w4[i * 2 + j] : 0.f;
+        } else if (g < 3) {                              // W3 (64,8)
+            v = j < 4 ? w.w3[(32 * (g - 1) + i) * 8 + j + 4 * h] : 0.f;
+        } else if (g >= 4) {
+            const int c = (g - 4) / TCH, q = (g - 4) % TCH;
+            if (q < 4) {                                 // W2 (256,64)
+                const int it = q >> 1, ks = q & 1;
+                v = w.w2[(32 * c + i) * 64 + 32 * it + chan(8 * ks + j, h)];
+            } else {                                     // W1 (128,256)
+                const int ot = (q - 4) >> 1, ks = q & 1;
+                v = w.w1[(32 * ot + i) * 256 + 32 * c + chan(8 * ks + j, h)];
+            }
+        }
+    } else {
+        const int k = (f - PT_BR) / PBR, g = (f - PT_BR) % PBR;
+        if (g < PB_K2) {                                 // D2 (64,128)
+            const int it = g >> 3, ot = (g >> 1) & 3, ks = g & 1;
+            v = w.d2[k][(32 * it + i) * 128 + 32 * ot + chan(8 * ks + j, h)];
+        } else if (g < PB_D1) {                          // K2 (1,2,64,32): [b][co][ci]
+            const int q = g - PB_K2, b = q >> 2, it = (q >> 1) & 1, ks = q & 1;
+            v = w.k2[k][(b * 64 + 32 * it + chan(8 * ks + j, h)) * 32 + i];
+        } else if (g < PB_K1) {                          // D1 (16,32)
+            const int ks = g - PB_D1;
+            v = i < 16 ? w.d1[k][i * 32 + chan(8 * ks + j, h)] : 0.f;
+        } else {                                         // K1 (2,1,16,128): [a][co][ci]
+            const int q = g - PB_K1, a = q >> 2, ot = q & 3;
+            v = w.k1[k][(a * 16 + chan(j, h)) * 128 + 32 * ot + i];
+        }
+    }
+    *(bf16_t*)(packt + ((long)(f * 64 + lane) * 8 + j) * 2) = (bf16_t)v;
+}
+
+__device__ __forceinline__ void zero_tile(f32x16& t) {
+#pragma unroll
+    for (int i = 0; i < 16; ++i) t[i] = 0.f;
+}
+
+__global__ __launch_bounds__(256, 1) void gblock_dgrad_bf16_kernel(const unsigned char* __restrict__ packt,
+                                                                   const float* __restrict__ dy,
+                                                                   bf16_t* __restrict__ delta, float* __restrict__ dx,
+                                                                   long pos0, long npix, int hl, int wl, long ntiles) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    const int lane = threadIdx.x & 63;
+    const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
+    const int r = lane & 31, h = lane >> 5;
+    unsigned char* kbuf = lds;                               // K0T fragments (8)
+    unsigned char* pbuf = lds + 8 * 1024;                    // two phase buffers
+    // phase q of a sub-row: 0 = tail-lo, 1 = tail-hi, 2..7 = branches
+    auto phase_f0 = [](int q) { return q == 0 ? PT_TAIL : (q == 1 ? PT_TAIL + PT_TAIL_LO : PT_BR + (q - 2) * PBR); };
+    auto phase_n = [](int q) { return q == 0 ? PT_TAIL_LO : (q == 1 ? PT_TAIL_HI : PBR); };
+
+    long tile = blockIdx.x;
+    if (tile >= ntiles) return;
+    stage(packt, PT_K0, 8, kbuf, wv, lane);
+    stage(packt, phase_f0(0), phase_n(0), pbuf, wv, lane);
+    __syncthreads();
+    int par = 0;
+    for (; tile < ntiles; tile += gridDim.x) {
+        const long p = pos0 + tile * 128 + wv * 32 + r;
+        const bool pvalid = p < npix;
+        const long pc = pvalid ? p : 0;
+        const long row = pc / wl;
+        const int jcol = (int)(pc - row * wl);
+        const float* dy0 = dy + ((row * 2) * (2L * wl) + 2L * jcol) * 2;      // output row 2i, column 2j
+        bf16_t* dt = delta + (tile * 4 + wv) * (GB_ROWS * 32L);
+        const bool more_tiles = tile + gridDim.x < ntiles;
+        f32x16 dF[4];
+#pragma unroll
+        for (int it = 0; it < 4; ++it) zero_tile(dF[it]);
+#pragma unroll 1
+        for (int a = 0; a < 2; ++a) {
+            f32x16 dS[2][4];
+            BTile dT2b[2][2];
+            // ---- tail: dY -> dT3 -> dT2, then per chunk c of Dense(256): dT1_c -> dS, both sub-columns ----
+#pragma unroll 1
+            for (int half = 0; half < 2; ++half) {
+                stage(packt, phase_f0(half + 1), phase_n(half + 1), pbuf + (par ^ 1) * TBUF_BYTES, wv, lane);
+                const unsigned char* wb = pbuf + par * TBUF_BYTES;
+                if (half == 0) {
+#pragma unroll
+                    for (int b = 0; b < 2; ++b) {
+                        const int ab = a * 2 + b;
+                        const float2 o = pvalid ? *(const float2*)(dy0 + (a * (2L * wl) + b) * 2) : make_float2(0.f, 0.f);
+                        // B operand: slots (h = 0, j < 2) carry dY as bf16, slots (h = 1, j < 2) the remainder
+                        const unsigned ohi = bf_pack(o.x, o.y);
+                        const unsigned olo = bf_pack(o.x - bf_lo(ohi), o.y - bf_hi(ohi));
+                        const u32x4 ob = (u32x4){h == 0 ? ohi : olo, 0u, 0u, 0u};
+                        f32x16 dT3;
+                        zero_tile(dT3);
+                        dT3 = mfma_bf16(frag(wb, 0, lane), ob, dT3);
+                        const BTile t3 = to_b(dT3);
+                        f32x16 dT2;
+#pragma unroll
+                        for (int ot = 0; ot < 2; ++ot) {
+                            zero_tile(dT2);
+                            dT2 = mfma_bf16(frag(wb, 1 + ot, lane), t3.k[0], dT2);
+                            dT2b[b][ot] = to_b(dT2);
+                            save_b<2>(dt, GB_T2 + ab * 64 + ot * 32, dT2b[b][ot], r, h);
+                        }
+                        if (h == 0) store_pair(dt, GB_X + ab * 2, r, ohi);
+#pragma unroll
+                        for (int q = 0; q < 2; ++q) store_pair(dt, GB_T3 + ab * 8 + 4 * h + 2 * q, r, t3.k[0][q]);
+#pragma unroll
+                        for (int ot = 0; ot < 4; ++ot) zero_tile(dS[b][ot]);
+                    }
+                }
+                const unsigned char* wch = wb + (half == 0 ? 4 * 1024 : 0);
+#pragma unroll 1
+                for (int cc = 0; cc < 4; ++cc) {
+                    const unsigned char* wc = wch + cc * TCH * 1024;
+                    const int c = half * 4 + cc;
+#pragma unroll
+                    for (int b = 0; b < 2; ++b) {
+                        f32x16 dT1;
+                        zero_tile(dT1);
+#pragma unroll
+                        for (int it = 0; it < 2; ++it)
+#pragma unroll
+                            for (int ks = 0; ks < 2; ++ks) dT1 = mfma_bf16(frag(wc, it * 2 + ks, lane), dT2b[b][it].k[ks], dT1);
+                        const BTile t1 = to_b(dT1);
+                        save_b<2>(dt, GB_T1 + (a * 2 + b) * 256 + c * 32, t1, r, h);
+#pragma unroll
+                        for (int ot = 0; ot < 4; ++ot)
+#pragma unroll
+                            for (int ks = 0; ks < 2; ++ks)
+                                dS[b][ot] = mfma_bf16(frag(wc, 4 + ot * 2 + ks, lane), t1.k[ks], dS[b][ot]);
+                    }
+                }
+                __syncthreads();
+                par ^= 1;
+            }
+            BTile dSb[2][4];
+#pragma unroll
+            for (int b = 0; b < 2; ++b)
+#pragma unroll
+                for (int ot = 0; ot < 4; ++ot) {
+                    dSb[b][ot] = to_b(dS[b][ot]);
+                    save_b<2>(dt, GB_S + (a * 2 + b) * 128 + ot * 32, dSb[b][ot], r, h);
+                }
+            // ---- branches ----
+#pragma unroll 1
+            for (int k = 0; k < 6; ++k) {
+                if (k < 5) stage(packt, phase_f0(k + 3), phase_n(k + 3), pbuf + (par ^ 1) * TBUF_BYTES, wv, lane);
+                else if (a == 0 || more_tiles) stage(packt, phase_f0(0), phase_n(0), pbuf + (par ^ 1) * TBUF_BYTES, wv, lane);
+                const unsigned char* wb = pbuf + par * TBUF_BYTES;
+                bf16_t* dbr = dt + (GB_BR + k * GB_BR_ROWS) * 32;
+                f32x16 do2;
+                zero_tile(do2);
+#pragma unroll
+                for (int b = 0; b < 2; ++b) {
+                    BTile do3b[2];
+#pragma unroll
+                    for (int it = 0; it < 2; ++it) {
+                        f32x16 do3;
+                        zero_tile(do3);
+#pragma unroll
+                        for (int ot = 0; ot < 4; ++ot)
+#pragma unroll
+                            for (int ks = 0; ks < 2; ++ks)
+                                do3 = mfma_bf16(frag(wb, PB_D2 + (it * 4 + ot) * 2 + ks, lane), dSb[b][ot].k[ks], do3);
+                        do3b[it] = to_b(do3);
+                        save_b<2>(dbr, GB_O3 + (a * 2 + b) * 64 + it * 32, do3b[it], r, h);
+                    }
+#pragma unroll
+                    for (int it = 0; it < 2; ++it)
+#pragma unroll
+                        for (int ks = 0; ks < 2; ++ks)
+                            do2 = mfma_bf16(frag(wb, PB_K2 + (b * 2 + it) * 2 + ks, lane), do3b[it].k[ks], do2);
+                }
+                const BTile do2b = to_b(do2);
+                save_b<2>(dbr, GB_O2 + a * 32, do2b, r, h);
+                f32x16 do1;
+                zero_tile(do1);
+                do1 = mfma_bf16(frag(wb, PB_D1, lane), do2b.k[0], do1);
+                do1 = mfma_bf16(frag(wb, PB_D1 + 1, lane), do2b.k[1], do1);
+                const BTile do1b = to_b(do1);
+                save_b<1>(dbr, GB_O1 + a * 16, do1b, r, h);          // rows 0-15 = registers 0-7 of both lane halves
+#pragma unroll
+                for (int ot = 0; ot < 4; ++ot)
+                    dF[ot] = mfma_bf16(frag(wb, PB_K1 + (a ? 4 : 0) + ot, lane), do1b.k[0], dF[ot]);
+                __syncthreads();
+                par ^= 1;
+            }
+        }
+        // ---- dX = (sum of the four taps of K0)^T dF; the up-sampling backward is that tap sum ----
+        f32x16 dxa;
+        zero_tile(dxa);
+#pragma unroll
+        for (int it = 0; it < 4; ++it) {
+            const BTile fb = to_b(dF[it]);
+            save_b<2>(dt, GB_F + it * 32, fb, r, h);
+            dxa = mfma_bf16(frag(kbuf, it * 2, lane), fb.k[0], dxa);
+            dxa = mfma_bf16(frag(kbuf, it * 2 + 1, lane), fb.k[1], dxa);
+        }
+        if (pvalid && h == 0) *(float2*)(dx + pc * 2) = make_float2(dxa[0], dxa[1]);
+    }
+}
+
 }  // namespace
 
 extern "C" int64_t mgx_gblock_pack_bf16_bytes(void) { return PACKB_BYTES; }
+extern "C" int64_t mgx_gblock_packt_bf16_bytes(void) { return (int64_t)NFT * 1024; }
 
-extern "C" int mgx_gblock_fwd_bf16(const mgx_gblock_weights* wp, void* packb, const float* x, float* y, int64_t nimg,
-                                   int hl, int wl, void* stream) {
-    if (!wp || !packb || !x || !y || nimg <= 0 || hl <= 0 || wl <= 0) return MGX_ERR_ARG;
-    const mgx_gblock_weights w = *wp;
+// bf16 elements of a side buffer (activations or gradients) for npos positions
+extern "C" int64_t mgx_gblock_side_elems_bf16(int64_t npos) {
+    return npos <= 0 ? 0 : ((npos + 127) / 128) * 4 * (GB_ROWS * 32L);
+}
+
+namespace {
+bool weights_set(const mgx_gblock_weights& w) {
     const void* const* ptrs = (const void* const*)&w;
     for (size_t i = 0; i < sizeof(w) / sizeof(void*); ++i)
-        if (!ptrs[i]) return MGX_ERR_ARG;
-    hipStream_t st = (hipStream_t)stream;
+        if (!ptrs[i]) return false;
+    return true;
+}
+}  // namespace
+
+extern "C" int mgx_gblock_fwd_bf16(const mgx_gblock_weights* wp, void* packb, const float* x, float* y, void* act,
+                                   int64_t nimg, int hl, int wl, int64_t pos0, int64_t npos, void* stream) {
+    if (!wp || !packb || !x || (!y && !act) || nimg <= 0 || hl <= 0 || wl <= 0) return MGX_ERR_ARG;
     const long npix = (long)nimg * hl * wl;
-    const long ntiles = (npix + 127) / 128;
-    hipLaunchKernelGGL(gblock_pack_bf16_kernel, dim3((NFB * 512 + 255) / 256), dim3(256), 0, st, w, (unsigned char*)packb);
-    if (hipFuncSetAttribute((const void*)gblock_fwd_bf16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) !=
+    if (pos0 < 0 || pos0 >= npix || (pos0 & 127)) return MGX_ERR_ARG;
+    const long end = (npos <= 0 || pos0 + npos > npix) ? npix : pos0 + npos;
+    const mgx_gblock_weights w = *wp;
+    if (!weights_set(w)) return MGX_ERR_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    const long ntiles = (end - pos0 + 127) / 128;
+    if (pos0 == 0)      // the packed fragments of a call sequence over ranges are filled by its first call
+        hipLaunchKernelGGL(gblock_pack_bf16_kernel, dim3((NFB * 512 + 255) / 256), dim3(256), 0, st, w, (unsigned char*)packb);
+    const unsigned grid = (unsigned)(ntiles < 256 ? ntiles : 256);
+    if (act) {
+        if (hipFuncSetAttribute((const void*)gblock_fwd_bf16_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                LDS_BYTES) != hipSuccess)
+            return MGX_ERR_LAUNCH;
+        hipLaunchKernelGGL(gblock_fwd_bf16_kernel<true>, dim3(grid), dim3(256), LDS_BYTES, st, (const unsigned char*)packb, x,
+                           y, (bf16_t*)act, (long)pos0, end, hl, wl, ntiles);
+    } else {
+        if (hipFuncSetAttribute((const void*)gblock_fwd_bf16_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                LDS_BYTES) != hipSuccess)
+            return MGX_ERR_LAUNCH;
+        hipLaunchKernelGGL(gblock_fwd_bf16_kernel<false>, dim3(grid), dim3(256), LDS_BYTES, st, (const unsigned char*)packb,
+                           x, y, (bf16_t*)nullptr, (long)pos0, end, hl, wl, ntiles);
+    }
+    return mgx_launch_status();
+}
+
+extern "C" int mgx_gblock_dgrad_bf16(const mgx_gblock_weights* wp, void* packt, const float* dy, void* delta, float* dx,
+                                     int64_t nimg, int hl, int wl, int64_t pos0, int64_t npos, void* stream) {
+    if (!wp || !packt || !dy || !delta || !dx || nimg <= 0 || hl <= 0 || wl <= 0) return MGX_ERR_ARG;
+    const long npix = (long)nimg * hl * wl;
+    if (pos0 < 0 || pos0 >= npix || (pos0 & 127)) return MGX_ERR_ARG;
+    const long end = (npos <= 0 || pos0 + npos > npix) ? npix : pos0 + npos;
+    const mgx_gblock_weights w = *wp;
+    if (!weights_set(w)) return MGX_ERR_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    const long ntiles = (end - pos0 + 127) / 128;
+    if (pos0 == 0)
+        hipLaunchKernelGGL(gblock_packT_bf16_kernel, dim3((NFT * 512 + 255) / 256), dim3(256), 0, st, w, (unsigned char*)packt);
+    if (hipFuncSetAttribute((const void*)gblock_dgrad_bf16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, TLDS_BYTES) !=
         hipSuccess)
         return MGX_ERR_LAUNCH;
     const unsigned grid = (unsigned)(ntiles < 256 ? ntiles : 256);
-    hipLaunchKernelGGL(gblock_fwd_bf16_kernel, dim3(grid), dim3(256), LDS_BYTES, st, (const unsigned char*)packb, x, y,
-                       npix, hl, wl, ntiles);
+    hipLaunchKernelGGL(gblock_dgrad_bf16_kernel, dim3(grid), dim3(256), TLDS_BYTES, st, (const unsigned char*)packt, dy,
+                       (bf16_t*)delta, dx, (long)pos0, end, hl, wl, ntiles);
     return mgx_launch_status();
 }

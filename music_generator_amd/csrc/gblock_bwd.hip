@@ -12,7 +12,7 @@
 //      operand.
 //   3. gblock_unpack_kernel: one thread per weight / bias element adds the slabs in split order
 //      (bitwise reproducible) into the Keras-layout gradient tensors.
-#include "common.h"
+#include "bf16.h"
 #include "gblock_frag.h"
 #include "gblock_rows.h"
 #include "../../include/mgx.h"
@@ -329,6 +329,96 @@ __global__ __launch_bounds__(256, 1) void gblock_wgrad_kernel(const float* __res
     for (int u = 0; u < TB; ++u) slab[TA * TB * 1024 + u * 64 + lane] = bs[u];
 }
 
+// The same weight-gradient jobs from bf16 side buffers on v_mfma_f32_32x32x16_bf16: a row of a side buffer
+// holds 32 positions = 64 bytes, so lane (channel i, half h) reads 16 bytes = the 8 contraction steps
+// 8h .. 8h+7 of k-step s at byte 32 s + 16 h of its row: operands still go straight from L2 / HBM to the
+// MFMA.  Accumulator tiles, slabs and the bias sums have the layout of the float32 kernel, so
+// gblock_unpack_kernel serves both.
+template <int TA, int TB>
+struct FragsB {
+    u32x4 a[TA][2], b[TB][2];
+};
+
+template <int TA, int TB>
+__device__ __forceinline__ void load_frags_b(FragsB<TA, TB>& f, const bf16_t* __restrict__ act,
+                                             const bf16_t* __restrict__ delta, const GJob& jb, long pt, int sub, int i,
+                                             int h) {
+    const bf16_t* pa = act + (pt * GB_ROWS + jb.rowA + sub * jb.strideA + i) * 32L + 8 * h;
+    const bf16_t* pb = delta + (pt * GB_ROWS + jb.rowB + sub * jb.strideB + i) * 32L + 8 * h;
+#pragma unroll
+    for (int t = 0; t < TA; ++t)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) f.a[t][ks] = *(const u32x4*)(pa + t * 1024 + ks * 16);
+#pragma unroll
+    for (int u = 0; u < TB; ++u)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) f.b[u][ks] = *(const u32x4*)(pb + u * 1024 + ks * 16);
+}
+
+template <int TA, int TB>
+__global__ __launch_bounds__(256, 1) void gblock_wgrad_bf16_kernel(const bf16_t* __restrict__ act,
+                                                                   const bf16_t* __restrict__ delta, GJobs jobs, int job0,
+                                                                   float* __restrict__ ws, long ntiles) {
+    int xb = blockIdx.x, jobi = blockIdx.y;
+    if ((gridDim.x & 7) == 0) {           // all jobs of one slab index on one XCD (see gblock_wgrad_kernel)
+        const unsigned lin = blockIdx.x + blockIdx.y * gridDim.x;
+        const unsigned q = lin >> 3;
+        jobi = (int)(q % gridDim.y);
+        xb = (int)((q / gridDim.y) * 8 + (lin & 7));
+    }
+    const GJob jb = jobs.j[job0 + jobi];
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int i = lane & 31, h = lane >> 5;
+    const long split = (long)xb * 4 + wv, nw = (long)gridDim.x * 4;
+    f32x16 acc[TA][TB];
+    float bs[TB];
+#pragma unroll
+    for (int t = 0; t < TA; ++t)
+#pragma unroll
+        for (int u = 0; u < TB; ++u) zero(acc[t][u]);
+#pragma unroll
+    for (int u = 0; u < TB; ++u) bs[u] = 0.f;
+
+    long pt = split;
+    int sub = 0;
+    FragsB<TA, TB> cur, nxt;
+    if (pt < ntiles) load_frags_b<TA, TB>(cur, act, delta, jb, pt, 0, i, h);
+    while (pt < ntiles) {
+        long ptn = pt;
+        int subn = sub + 1;
+        if (subn == jb.nsub) { subn = 0; ptn = pt + nw; }
+        const bool more = ptn < ntiles;
+        if (more) load_frags_b<TA, TB>(nxt, act, delta, jb, ptn, subn, i, h);
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+            for (int t = 0; t < TA; ++t)
+#pragma unroll
+                for (int u = 0; u < TB; ++u) acc[t][u] = mfma_bf16(cur.a[t][ks], cur.b[u][ks], acc[t][u]);
+        if (jb.bias) {
+#pragma unroll
+            for (int u = 0; u < TB; ++u)
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks)
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) bs[u] += bf_lo(cur.b[u][ks][q]) + bf_hi(cur.b[u][ks][q]);
+        }
+        MGX_FENCE();
+        if (more) cur = nxt;
+        pt = ptn;
+        sub = subn;
+    }
+    float* slab = ws + jb.ws_off + split * (TA * TB * 1024L + TB * 64L);
+#pragma unroll
+    for (int t = 0; t < TA; ++t)
+#pragma unroll
+        for (int u = 0; u < TB; ++u)
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) slab[((t * TB + u) * 16 + reg) * 64 + lane] = acc[t][u][reg];
+#pragma unroll
+    for (int u = 0; u < TB; ++u) slab[TA * TB * 1024 + u * 64 + lane] = bs[u];
+}
+
 // job numbering (see build_jobs): 0-3 W1, 4-9 D2_k, 10-11 W2, 12 W3, 13 W4, 14-19 D1_k,
 // 20-31 K2_k[b], 32-37 K1_k, 38 K0
 struct JobShape {
@@ -514,6 +604,13 @@ void launch_wgrad(const ShapeRun& run, const float* act, const float* delta, con
     hipLaunchKernelGGL((gblock_wgrad_kernel<TA, TB>), grid, dim3(256), 0, st, act, delta, J, run.job0, ws, ntiles);
 }
 
+template <int TA, int TB>
+void launch_wgrad_b(const ShapeRun& run, const bf16_t* act, const bf16_t* delta, const GJobs& J, float* ws, long ntiles,
+                    hipStream_t st) {
+    dim3 grid(grid_x(ntiles, run), run.njobs);
+    hipLaunchKernelGGL((gblock_wgrad_bf16_kernel<TA, TB>), grid, dim3(256), 0, st, act, delta, J, run.job0, ws, ntiles);
+}
+
 bool all_set(const void* strukt, size_t bytes) {
     const void* const* ptrs = (const void* const*)strukt;
     for (size_t i = 0; i < bytes / sizeof(void*); ++i)
@@ -573,6 +670,30 @@ extern "C" int mgx_gblock_wgrad_f32(const float* act, const float* delta, const 
     launch_wgrad<1, 2>(kRuns[4], act, delta, J, ws, ntiles, st);
     launch_wgrad<4, 1>(kRuns[5], act, delta, J, ws, ntiles, st);
     launch_wgrad<1, 4>(kRuns[6], act, delta, J, ws, ntiles, st);
+    hipLaunchKernelGGL(gblock_unpack_kernel, dim3((N_PARAMS * 8 + 255) / 256), dim3(256), 0, st, g, J, ws);
+    return mgx_launch_status();
+}
+
+extern "C" int mgx_gblock_wgrad_bf16(const void* act, const void* delta, const mgx_gblock_grads* gp, void* workspace,
+                                     int64_t workspace_bytes, int64_t npos, void* stream) {
+    if (!act || !delta || !gp || !workspace || npos <= 0) return MGX_ERR_ARG;
+    const mgx_gblock_grads g = *gp;
+    if (!all_set(&g, sizeof(g))) return MGX_ERR_ARG;
+    const long ntiles = ((npos + 127) / 128) * 4;
+    GJobs J;
+    const long need = build_jobs(J, ntiles);
+    if (workspace_bytes < need * (int64_t)sizeof(float)) return MGX_ERR_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    float* ws = (float*)workspace;
+    const bf16_t* a = (const bf16_t*)act;
+    const bf16_t* d = (const bf16_t*)delta;
+    launch_wgrad_b<2, 4>(kRuns[0], a, d, J, ws, ntiles, st);
+    launch_wgrad_b<4, 2>(kRuns[1], a, d, J, ws, ntiles, st);
+    launch_wgrad_b<2, 1>(kRuns[2], a, d, J, ws, ntiles, st);
+    launch_wgrad_b<1, 1>(kRuns[3], a, d, J, ws, ntiles, st);
+    launch_wgrad_b<1, 2>(kRuns[4], a, d, J, ws, ntiles, st);
+    launch_wgrad_b<4, 1>(kRuns[5], a, d, J, ws, ntiles, st);
+    launch_wgrad_b<1, 4>(kRuns[6], a, d, J, ws, ntiles, st);
     hipLaunchKernelGGL(gblock_unpack_kernel, dim3((N_PARAMS * 8 + 255) / 256), dim3(256), 0, st, g, J, ws);
     return mgx_launch_status();
 }

@@ -295,33 +295,51 @@ def _register_fused_block(block_end, upsampling, for_sum_layer):
         n, hl, wl, _ = x.shape
         y = K.empty((n, 2 * hl, 2 * wl, 2))
         if K.bf16_enabled():
-            if "packb" not in state:
-                state["packb"] = torch.empty((ops.gblock_pack_bf16_bytes(),), dtype=torch.uint8, device=x.device)
-            ops.gblock_fwd_bf16(w, state["packb"], x, y, n, hl, wl)
+            ops.gblock_fwd_bf16(w, packb(x), x, y, n, hl, wl)
         else:
             ops.gblock_fwd(w, state["pack"], x, y, n, hl, wl)
         return y
 
+    def packb(x):
+        if "packb" not in state:
+            state["packb"] = torch.empty((ops.gblock_pack_bf16_bytes(),), dtype=torch.uint8, device=x.device)
+        return state["packb"]
+
     def run_save(x):
         """Taped forward.  With enough memory the block's intermediate tensors are kept (one
-        tile-major buffer); above FusedGroup.side_budget_bytes only the 2-channel input is kept and
-        the backward re-computes them range by range."""
+        tile-major buffer, bf16 under the bf16 precision); above FusedGroup.side_budget_bytes only the
+        2-channel input is kept and the backward re-computes them range by range."""
         w = weights()
         n, hl, wl, _ = x.shape
-        y = K.empty((n, 2 * hl, 2 * wl, 2))
-        side = ops.gblock_side_floats(n * hl * wl)
+        bf = K.bf16_enabled()
+        side = ops.gblock_side_elems_bf16(n * hl * wl) if bf else ops.gblock_side_floats(n * hl * wl)
         budget = FusedGroup.side_budget_bytes
-        if budget is not None and 4 * side > budget:
-            return run(x), (None, x, (n, hl, wl))
-        act = K.empty((side,))
-        ops.gblock_fwd(w, state["pack"], x, y, n, hl, wl, act=act)
-        return y, (act, None, (n, hl, wl))
+        if budget is not None and (2 if bf else 4) * side > budget:
+            return run(x), (None, x, (n, hl, wl), bf)
+        y = K.empty((n, 2 * hl, 2 * wl, 2))
+        act = K.empty((side,), dtype=torch.bfloat16 if bf else torch.float32)
+        if bf:
+            ops.gblock_fwd_bf16(w, packb(x), x, y, n, hl, wl, act=act)
+        else:
+            ops.gblock_fwd(w, state["pack"], x, y, n, hl, wl, act=act)
+        return y, (act, None, (n, hl, wl), bf)
 
     def backward(saved, dy, need_weight_grads):
-        act, x, (n, hl, wl) = saved
+        act, x, (n, hl, wl), bf = saved
         w = weights()
-        if "packt" not in state:
-            state["packt"] = K.empty((ops.gblock_packt_floats(),))
+        if bf:
+            if "packtb" not in state:
+                state["packtb"] = torch.empty((ops.gblock_packt_bf16_bytes(),), dtype=torch.uint8, device=dy.device)
+            packt = state["packtb"]
+        else:
+            if "packt" not in state:
+                state["packt"] = K.empty((ops.gblock_packt_floats(),))
+            packt = state["packt"]
+        fwd = (lambda **kw: ops.gblock_fwd_bf16(w, packb(dy), x, None, n, hl, wl, **kw)) if bf else \
+              (lambda **kw: ops.gblock_fwd(w, state["pack"], x, None, n, hl, wl, **kw))
+        dgrad = ops.gblock_dgrad_bf16 if bf else ops.gblock_dgrad
+        wgrad = ops.gblock_wgrad_bf16 if bf else ops.gblock_wgrad
+        side_of = ops.gblock_side_elems_bf16 if bf else ops.gblock_side_floats
         grads = None
         if need_weight_grads:
             for layer, _, _, _ in layer_fields:
@@ -331,24 +349,27 @@ def _register_fused_block(block_end, upsampling, for_sum_layer):
         dx = K.empty((n, hl, wl, 2))
         total = n * hl * wl
         if act is not None:
-            delta = K.empty((ops.gblock_side_floats(total),))
-            ops.gblock_dgrad(w, state["packt"], dy, delta, dx, n, hl, wl)
+            delta = K.empty((side_of(total),), dtype=torch.bfloat16 if bf else torch.float32)
+            dgrad(w, packt, dy, delta, dx, n, hl, wl)
             if grads is not None:
-                ops.gblock_wgrad(act, delta, grads, total)
+                wgrad(act, delta, grads, total)
             return dx
         # re-computation: ranges of positions sized so that both side buffers fit the budget
-        per_pos = 4 * ops.gblock_side_floats(128) // 128
+        esize = 2 if bf else 4
+        per_pos = esize * side_of(128) // 128
         step = max(128, (FusedGroup.side_budget_bytes // (2 * per_pos)) // 128 * 128)
         step = min(step, (total + 127) // 128 * 128)
-        floats = ops.gblock_side_floats(step)
-        bufs = K.side_buffers(floats)
+        elems = side_of(step)
+        bufs = K.side_buffers((elems + 1) // 2 if bf else elems)
+        if bf:
+            bufs = [b.view(torch.bfloat16) for b in bufs]
         for pos0 in range(0, total, step):
             cnt = min(step, total - pos0)
             if grads is not None:
-                ops.gblock_fwd(w, state["pack"], x, None, n, hl, wl, act=bufs[0], pos0=pos0, npos=cnt)
-            ops.gblock_dgrad(w, state["packt"], dy, bufs[1], dx, n, hl, wl, pos0=pos0, npos=cnt)
+                fwd(act=bufs[0], pos0=pos0, npos=cnt)
+            dgrad(w, packt, dy, bufs[1], dx, n, hl, wl, pos0=pos0, npos=cnt)
             if grads is not None:
-                ops.gblock_wgrad(bufs[0], bufs[1], grads, cnt)
+                wgrad(bufs[0], bufs[1], grads, cnt)
         return dx
 
     group = FusedGroup(block_end, for_sum_layer, nodes, [upsampling.node], run)

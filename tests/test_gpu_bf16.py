@@ -432,3 +432,52 @@ def test_bf16_generator_forward_matches_oracle(stage, batch):
     print("generator audio: rel-L2", err, "max abs", np.abs(got - want).max())
     assert err <= 2e-2, err
     assert np.abs(got - want).max() <= 8e-2 * np.abs(want).max()
+
+
+@pytest.mark.parametrize("stage,twin,budget", [(1, 0, None), (2, 1, None), (2, 0, 64 << 20)])
+def test_bf16_generator_backward_matches_oracle(stage, twin, budget):
+    """Taped generator forward + backward with the grow blocks on the bf16 fused kernels (tape and gradient
+    side buffers in bf16; with `budget` the re-computing backward over position ranges) against float64
+    autograd of the oracle for a random output gradient.  The chain is linear: every intermediate
+    activation / gradient is rounded to bf16 once.  Tolerance: audio relative L2 <= 2e-2; weight and bias
+    gradients of the grow blocks relative L2 <= 3e-2 per tensor (5e-2 for the few tensors with < 64
+    elements); gradients of the float32 stage-0 layers and the LayerNormalization <= 3e-2."""
+    from music_generator_amd.graph import FusedGroup
+    d, g, comp, W = _build(stage + 1)
+    model = g[stage][twin]
+    for layer in model.layers:
+        if isinstance(layer, M.WeightedSum):
+            M.backend.set_value(layer.alpha, 0.37)
+    batch = 2
+    _, z4 = R.synthetic_inputs(stage, batch, seed=0)
+    h, w = 4 << stage, 750 << stage
+    rng = np.random.default_rng(9)
+    dy = rng.standard_normal((batch, h, w, 2)).astype(np.float32)
+    M.backend.set_precision("bfloat16")
+    FusedGroup.side_budget_bytes = budget
+    try:
+        y, tape = model.forward(torch.from_numpy(z4[0]).cuda(), save=True)
+        model.bind_grads().zero_()
+        model.backward(tape, torch.from_numpy(dy).cuda(), need_input_grad=False)
+        torch.cuda.synchronize()
+    finally:
+        M.backend.set_precision("float32")
+        FusedGroup.side_budget_bytes = None
+    got = {v.name: v.grad.cpu().numpy().reshape(v.shape).copy() for v in model.trainable_variables}
+    names = R.layer_names(stage + 1)
+    Wt = {k: torch.tensor(np.asarray(v), dtype=torch.float64, requires_grad=True) for k, v in W.items()}
+    al = None
+    if twin:
+        al = torch.tensor(0.37, dtype=torch.float64, requires_grad=True)
+        Wt[names["g"][stage]["ws"] + "/alpha"] = al
+    yo = R.generator(Wt, names, stage, bool(twin), torch.tensor(z4[0], dtype=torch.float64), al)
+    keys = R.trainable_names(names, stage, bool(twin), "g")
+    gs = torch.autograd.grad((yo * torch.tensor(dy, dtype=torch.float64)).sum(), [Wt[k] for k in keys])
+    assert rel_l2(y.cpu().numpy(), yo.detach().numpy()) <= 2e-2
+    assert set(keys) == set(got), sorted(set(keys) ^ set(got))
+    errs = {k: rel_l2(got[k], gr.numpy()) for k, gr in zip(keys, gs)}
+    print("audio", rel_l2(y.cpu().numpy(), yo.detach().numpy()), "worst gradients",
+          sorted(errs.items(), key=lambda kv: -kv[1])[:4])
+    for k, err in errs.items():
+        tol = 2e-1 if k.endswith("/alpha") else (5e-2 if got[k].size < 64 else 3e-2)
+        assert err <= tol, "%s: rel-L2 %.3e" % (k, err)
