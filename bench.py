@@ -21,7 +21,12 @@ Rank 0 prints ONE JSON line with, beside the contract fields,
   per_stage        (N = 1) samples/s of the fade-in step at every progressive stage 0-6, fp32 and bf16;
   c3               (N = 1) BASELINE configs[2]: the full-resolution stage (256 x 48000), batch 256 in
                    micro-batches of one MinibatchStdDev group, bf16: one timed step after a warm-up on 8
-                   samples, with the roofline of its dominant kernel against the bf16 dense MFMA peak.
+                   samples, with the roofline of its dominant kernel against the bf16 dense MFMA peak;
+  c5               (N = 1) BASELINE configs[4]: generator-only inference at the final stage through
+                   music_generator_amd.inference.generate_clips, clips/s in fp32 and bf16.
+
+    python bench.py --infer [--clips 4096] [--chunk 8] [--precision bfloat16]
+prints the inference line alone (metric "generator inference clips/s"; a step is one chunk).
 """
 import argparse
 import json
@@ -64,6 +69,10 @@ def parse_args():
                     help="evaluate discriminator(real) once after the D update instead of three times (same values)")
     ap.add_argument("--cpu-sample-batch", type=int, default=2)
     ap.add_argument("--c3-batch", type=int, default=256)
+    ap.add_argument("--infer", action="store_true", help="generator-only inference line (BASELINE configs[4])")
+    ap.add_argument("--clips", type=int, default=256, help="--infer: clips to generate in the timed region")
+    ap.add_argument("--chunk", type=int, default=8, help="--infer: clips per generator call")
+    ap.add_argument("--infer-stage", type=int, default=6)
     ap.add_argument("--graph", action="store_true",
                     help="replay the step as one HIP graph (WGAN.use_graph): for small batches, where the host's "
                          "launch rate bounds the step; no per-kernel roofline in this mode")
@@ -234,6 +243,59 @@ def c3_run(torch, M, ops, batch):
     return out
 
 
+def infer_run(torch, M, ops, precision, stage, clips, chunk):
+    """BASELINE configs[4]: `clips` latent vectors -> audio through generate_clips in chunks, every chunk
+    reduced on the device to per-clip checksums (a 4096-clip run at the final stage is 403 GB of float32
+    audio: it is consumed chunk by chunk, never resident).  One warm-up chunk, then the timed run."""
+    from music_generator_amd.inference import ChecksumSink, generate_clips
+    M.backend.set_precision(precision)
+    M.clear_session()
+    torch.cuda.empty_cache()
+    g = M.define_generator(stage + 1)[stage][0]
+    generate_clips(g, chunk, chunk, ChecksumSink(), seed=1)
+    torch.cuda.synchronize()
+    torch.cuda.reset_peak_memory_stats()
+    sink = ChecksumSink()
+    prof = ops.LaunchProfiler()
+    ops.PROFILER = prof
+    t0 = time.perf_counter()
+    n = generate_clips(g, clips, chunk, sink, seed=2)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    ops.PROFILER = None
+    chk = sink.result()
+    h, w = 4 << stage, 750 << stage
+    summ = prof.summary()
+    peak = BF16_MFMA_PEAK_TFLOPS if precision == "bfloat16" else F32_MFMA_PEAK_TFLOPS
+    nchunks = (clips + chunk - 1) // chunk
+    _, roof = roofline_of(summ, nchunks, dt * 1e3 / nchunks, peak)
+    out = {"metric": "generator inference clips/s", "value": round(n / dt, 3), "unit": "clips/s", "n_gpus": 1,
+           "steps": nchunks, "warmup": 1, "ms_per_step": round(dt / nchunks * 1e3, 3), "higher_is_better": True,
+           "scaling": "weak", "vs_baseline": None, "dtype": "f32" if precision == "float32" else "bf16",
+           "data": "synthetic (standard-normal latent vectors)",
+           "config": {"workload": "generator-only inference, stage %d (%dx%d), %d clips in chunks of %d, audio reduced "
+                                  "to per-clip checksums on the device" % (stage, h, w, clips, chunk)},
+           "seconds_for_4096_clips": round(4096 * dt / n, 1),
+           "gflop_per_clip": round(sum(v[2] for v in summ.values()) / n / 1e9, 1),
+           "tflops_algorithmic": round(sum(v[2] for v in summ.values()) / dt / 1e12, 1),
+           "finite": bool(np_isfinite(chk)), "clip_mean_abs_max": float(abs(chk[:, 0]).max() / (h * w * 2)),
+           "clip_mean_square_range": [float(chk[:, 1].min() / (h * w * 2)), float(chk[:, 1].max() / (h * w * 2))],
+           "peak_hbm_gib": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1),
+           "roofline": roof,
+           "hbm_ops": {k: {"launches": v[0], "ms": round(v[1], 3), "bytes_per_launch": round(v[3] / v[0]),
+                           "GB/s": round(v[3] / v[1] / 1e6, 1), "frac_of_8TBps": round(v[3] / v[1] / 1e6 / 8000.0, 3)}
+                       for k, v in summ.items() if v[2] == 0.0 and v[1] > 0}}
+    del g
+    torch.cuda.empty_cache()
+    M.backend.set_precision("float32")
+    return out
+
+
+def np_isfinite(a):
+    import numpy as np
+    return np.isfinite(a).all()
+
+
 def main():
     args = parse_args()
     world = int(os.environ.get("WORLD_SIZE", "1"))
@@ -247,6 +309,13 @@ def main():
     import music_generator_amd as M
     from music_generator_amd import ops
     from music_generator_amd.parallel import DataParallel
+
+    if args.infer:
+        if world > 1:
+            raise SystemExit("--infer is a single-GPU line (clips are independent: run one process per GPU)")
+        torch.cuda.set_device(0)
+        print(json.dumps(infer_run(torch, M, ops, args.precision, args.infer_stage, args.clips, args.chunk)))
+        return
 
     # one rank per GPU; MGX_BENCH_BACKEND=gloo rehearses the multi-rank flow on a box with fewer GPUs
     # than ranks (RCCL refuses two ranks on one device)
@@ -347,6 +416,14 @@ def main():
         if not args.no_extras:
             out["per_stage"] = per_stage_table(torch, M)
             out["c3"] = c3_run(torch, M, ops, args.c3_batch)
+            out["c5"] = {}
+            for precision in ("float32", "bfloat16"):
+                r = infer_run(torch, M, ops, precision, 6, 64, 8)
+                out["c5"]["f32" if precision == "float32" else "bf16"] = {
+                    k: r[k] for k in ("value", "unit", "seconds_for_4096_clips", "gflop_per_clip", "tflops_algorithmic", "roofline",
+                                      "hbm_ops", "peak_hbm_gib", "finite")}
+                out["c5"]["workload"] = r["config"]["workload"]
+                progress("c5 %s: %.1f clips/s" % (precision, r["value"]))
         if not args.no_cpu_baseline:
             progress("CPU baseline")
             out["cpu_baseline"] = cpu_baseline(stage, fade, args.cpu_sample_batch, n_blocks)

@@ -13,10 +13,26 @@ import torch
 _name_counts: Dict[str, int] = {}
 
 
+# Counts every event that moves or drops a scratch buffer whose raw address kernels are handed
+# (workspace / side-buffer growth, clear_session).  A captured HIP graph has those addresses baked
+# into its launches: it records the count at capture time and is re-captured when the count moved.
+_buffer_generation = [0]
+
+
+def buffer_generation() -> int:
+    return _buffer_generation[0]
+
+
+def live_scratch():
+    """The scratch tensors currently handed out (a graph keeps them referenced while it may replay)."""
+    return list(_workspace.values()) + [t for pair in _side.values() for t in pair]
+
+
 def clear_session():
     """Reset the auto-naming counters (keras.backend.clear_session analogue)."""
     _name_counts.clear()
     _side.clear()
+    _buffer_generation[0] += 1
 
 
 def unique_name(cls_name: str) -> str:
@@ -143,6 +159,7 @@ def workspace(nbytes: int) -> torch.Tensor:
         _workspace.pop(key, None)
         cur = torch.empty(max(int(nbytes), 1 << 20), dtype=torch.uint8, device=dev)
         _workspace[key] = cur
+        _buffer_generation[0] += 1
     return cur
 
 
@@ -161,6 +178,7 @@ def side_buffers(nfloats: int):
         cur = None
         cur = [torch.empty((int(nfloats),), dtype=torch.float32, device=dev) for _ in range(2)]
         _side[key] = cur
+        _buffer_generation[0] += 1
     return cur
 
 

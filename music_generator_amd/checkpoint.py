@@ -61,9 +61,14 @@ def save_checkpoint(path: str, d_models, g_models, gan_models, stage: int = 0, f
                    "train_steps": None if gan.train_steps is None else int(gan.train_steps), "optimisers": {}}
             for tag, opt, _model in _optimisers(gan):
                 has_v = opt._state is not None
-                rec["optimisers"][tag] = {"iterations": int(opt.iterations), "has_v": has_v}
+                has_m = has_v and opt._state["m"] is not None
+                rec["optimisers"][tag] = {"iterations": int(opt.iterations), "has_v": has_v, "has_m": has_m,
+                                          "lr": opt.lr, "beta_1": opt.beta_1, "beta_2": opt.beta_2,
+                                          "epsilon": opt.epsilon}
                 if has_v:
                     arrays["adam_%d_%d_%s" % (s, t, tag)] = opt._state["v"].detach().cpu().numpy()
+                if has_m:
+                    arrays["adam_%d_%d_%s_m" % (s, t, tag)] = opt._state["m"].detach().cpu().numpy()
             rec["has_rng"] = gan._rng is not None
             if gan._rng is not None:                      # latent draws of a seeded WGAN continue where they stopped
                 arrays["rng_%d_%d" % (s, t)] = gan._rng.get_state().cpu().numpy()
@@ -109,6 +114,15 @@ def load_checkpoint(path: str, d_models, g_models, gan_models) -> Dict:
             gan.train_steps = rec["train_steps"]
             for tag, opt, model in _optimisers(gan):
                 o = rec["optimisers"][tag]
+                for hp in ("lr", "beta_1", "beta_2", "epsilon"):
+                    if hp in o and abs(float(o[hp]) - float(getattr(opt, hp))) > 1e-12 * max(1.0, abs(float(o[hp]))):
+                        raise ValueError("Adam of stage %d twin %d %s: checkpoint has %s = %r, the optimiser %r"
+                                         % (rec["stage"], rec["twin"], tag, hp, o[hp], getattr(opt, hp)))
+                if o["has_v"] and bool(o.get("has_m", False)) != (opt.beta_1 != 0.0):
+                    raise ValueError("Adam of stage %d twin %d %s: the checkpoint %s a first moment, the optimiser "
+                                     "(beta_1 = %g) %s one" % (rec["stage"], rec["twin"], tag,
+                                                               "holds" if o.get("has_m") else "lacks", opt.beta_1,
+                                                               "keeps" if opt.beta_1 != 0.0 else "does not keep"))
                 opt.iterations = o["iterations"]
                 if o["has_v"]:
                     if opt._state is None:
@@ -118,8 +132,14 @@ def load_checkpoint(path: str, d_models, g_models, gan_models) -> Dict:
                         raise ValueError("Adam state of stage %d twin %d %s: %d values, expected %d"
                                          % (rec["stage"], rec["twin"], tag, v.size, opt._state["v"].numel()))
                     opt._state["v"].copy_(torch.from_numpy(np.ascontiguousarray(v)))
-                else:
-                    opt._state = None
+                    if o.get("has_m"):
+                        m = f["adam_%d_%d_%s_m" % (rec["stage"], rec["twin"], tag)]
+                        opt._state["m"].copy_(torch.from_numpy(np.ascontiguousarray(m)))
+                elif opt._state is not None:
+                    # zeroed in place: a captured HIP graph may hold the addresses of these tensors
+                    opt._state["v"].zero_()
+                    if opt._state["m"] is not None:
+                        opt._state["m"].zero_()
             if rec.get("has_rng"):
                 if gan._rng is None:
                     gan.seed(0)

@@ -492,6 +492,22 @@ class Adam:
         ops.adam_multi(st["p"], st["n"], st["off"], model.bind_grads(), st["v"], st["blk_t"], st["blk_s"],
                        st["nblocks"], lr_t, self.beta_2, self.epsilon)
 
+    def set_second_moments(self, model: Model, values: Dict[str, np.ndarray], iterations: int):
+        """Load the second-moment estimate of every trainable variable of `model` (by variable name) and the
+        count of updates already applied: the state a resumed or externally warmed optimiser continues from."""
+        if self._state is None:
+            self._build(model)
+        if self._state["model"] is not model:
+            raise RuntimeError("an Adam instance is bound to the first model it updates")
+        flat = np.zeros(self._state["v"].numel(), np.float32)
+        for var, off, n in model.grad_layout():
+            a = np.asarray(values[var.name], np.float32).reshape(-1)
+            if a.size != n:
+                raise ValueError("second moment of %s has %d elements, the variable %d" % (var.name, a.size, n))
+            flat[off:off + n] = a
+        self._state["v"].copy_(torch.from_numpy(flat))
+        self.iterations = int(iterations)
+
     def second_moments(self) -> Dict[str, np.ndarray]:
         if self._state is None:
             return {}
@@ -531,6 +547,10 @@ class WGAN:
         # True: train_step captures the whole step into one HIP graph (per batch shape) the second
         # time it sees a shape and replays it from then on; see _graphed_step.
         self.use_graph = False
+        # True: the discriminator step keeps its logits (last_logits = {"fake", "real"}: (n,) device tensors in
+        # batch order) for comparison against a reference; off by default (one gather per step)
+        self.keep_logits = False
+        self.last_logits = None
         self._graphs: Dict = {}
         self._scalars = None                  # device [alpha, lr_t of D, lr_t of G] while capturing
         self._mb_cache: Dict = {}
@@ -677,7 +697,10 @@ class WGAN:
             raise RuntimeError("injected latents cannot be used with use_graph (the graph draws its own)")
         if ops.PROFILER is not None:
             raise RuntimeError("per-launch profiling and graph capture exclude each other")
-        key = tuple(real.shape)
+        # a graph is valid for one batch shape, one set of step-shaping options and one generation of the
+        # scratch buffers whose addresses its launches carry
+        key = (tuple(real.shape), self.micro_batch, self.generator_chunk, self.reuse_real_logits,
+               FusedGroup.side_budget_bytes, K.precision())
         entry = self._graphs.get(key)
         alpha = self._fade_alpha()
         if entry is None:                       # first sight of this shape: ordinary step, caches warm up
@@ -688,15 +711,21 @@ class WGAN:
             out = self._step_body(real)
             self.actual_step += 1
             return out
+        if entry["graph"] is not None and entry["generation"] != K.buffer_generation():
+            # a scratch buffer moved since the capture (a larger shape, another model, clear_session): the
+            # old graph would write through stale addresses, so it is dropped and this shape captured again
+            entry["graph"] = None
         if entry["graph"] is None:
-            entry["real"] = torch.empty_like(real)
-            entry["scal"] = torch.zeros((3,), dtype=torch.float32, device=real.device)
-            entry["host"] = torch.zeros((3,), dtype=torch.float32).pin_memory()
+            if "real" not in entry:
+                entry["real"] = torch.empty_like(real)
+                entry["scal"] = torch.zeros((3,), dtype=torch.float32, device=real.device)
+                entry["host"] = torch.zeros((3,), dtype=torch.float32).pin_memory()
             graph = torch.cuda.CUDAGraph()
             if self._rng is not None:
                 graph.register_generator_state(self._rng)
             torch.cuda.synchronize()
             self._scalars = entry["scal"]
+            generation = K.buffer_generation()
             try:
                 with torch.cuda.graph(graph):
                     if alpha is not None:
@@ -705,7 +734,11 @@ class WGAN:
                     entry["out"] = self._step_body(entry["real"])
             finally:
                 self._scalars = None
-            entry["graph"] = graph
+            if K.buffer_generation() != generation:
+                raise RuntimeError("a scratch buffer was reallocated while the step was being captured; the "
+                                   "eager step before the capture must see the same shapes")
+            entry["graph"], entry["generation"] = graph, generation
+            entry["scratch"] = K.live_scratch()      # referenced as long as this graph may replay
         host = entry["host"]
         host[0] = 0.0 if alpha is None else alpha
         host[1] = self.d_optimizer.next_step_size()
@@ -732,6 +765,7 @@ class WGAN:
             flat_r.zero_()
             sums = K.zeros((2,))
             pending = pending_r = None
+            kept = [] if self.keep_logits else None
             for bi, idx in enumerate(batches):
                 zb, rb = self._take(z, idx), self._take(real, idx)
                 ones = self._ones(rb.shape[0])
@@ -753,6 +787,18 @@ class WGAN:
                     # the real-pass sums are final too: reduced beside the logit sums / loss kernel below
                     pending_r = self.dist.all_reduce_async(flat_r)
                 ops.logit_sums(fake_logits.view(-1), real_logits.view(-1), sums, accumulate=True)
+                if kept is not None:
+                    kept.append((idx, fake_logits.view(-1).clone(), real_logits.view(-1).clone()))
+            if kept is not None:
+                self.last_logits = {}
+                for j, key in ((1, "fake"), (2, "real")):
+                    full = K.empty((n,))
+                    for item in kept:
+                        if item[0] is None:
+                            full.copy_(item[j])
+                        else:
+                            full.index_copy_(0, item[0], item[j])
+                    self.last_logits[key] = full
             out_d, cf, cr = self._finish_sums(sums, 0, n, True)
             if self.dist is not None:
                 self.dist.wait_for(pending)
@@ -817,17 +863,23 @@ class WGAN:
         self.last_losses = {"d_loss": out_d[0], "g_loss": out_g[0]}
         return {"delta_0": m0[3], "cu_0": m0[1], "ci_0": m0[2], "delta_1": m1[3], "cu_1": m1[1], "ci_1": m1[2]}
 
-    def fit(self, x, batch_size=32, epochs=1, callbacks=None, shuffle=True, verbose=0, initial_epoch=0):
+    def fit(self, x, batch_size=32, epochs=1, callbacks=None, shuffle=True, verbose=0, initial_epoch=0,
+            shuffle_seed=0):
         """keras.Model.fit for this custom step: per epoch a fresh permutation, full passes in
         batches, History holds the last batch's metrics of every epoch.  `initial_epoch` (Keras'
         argument of the same name) resumes a run: the permutations of the finished epochs are
-        drawn and dropped so that the remaining epochs see the batches they would have seen."""
+        drawn and dropped so that the remaining epochs see the batches they would have seen.
+        `shuffle_seed` seeds the permutation stream of this call.
+        With a DataParallel attached (`self.dist`), `x` is the same full data set on every rank and
+        `batch_size` the GLOBAL batch: every rank draws the same permutation and steps on its own
+        MinibatchStdDev groups of each global batch (parallel.shard_indices), so R ranks walk the
+        trajectory of one process; a global batch whose groups do not split over the ranks raises."""
         callbacks = list(callbacks or [])
         for cb in callbacks:
             cb.model = self
         hist = History()
         n = x.shape[0]
-        rng = np.random.default_rng(0)
+        rng = np.random.default_rng(shuffle_seed)
         for epoch in range(epochs):
             order = rng.permutation(n) if shuffle else np.arange(n)
             if epoch < initial_epoch:
@@ -835,6 +887,9 @@ class WGAN:
             logs = None
             for i in range(0, n, batch_size):
                 idx = order[i:i + batch_size]
+                if self.dist is not None and self.dist.world_size > 1:
+                    from .parallel import shard_indices
+                    idx = idx[shard_indices(len(idx), self.dist.rank, self.dist.world_size)]
                 logs = self.train_step(x[idx])
             logs = {k: float(v) for k, v in (logs or {}).items()}
             for k, v in logs.items():

@@ -220,8 +220,12 @@ def test_weighted_sum(alpha):
     yo = R.weighted_sum(ya, yb, al)
     gs = torch.autograd.grad((yo * torch.tensor(dy, dtype=torch.float64)).sum(), [xt, al] + list(wt.values()))
     assert_close(y, yo.detach().numpy(), TOL, "blend")
-    if alpha == 0.0:
-        assert np.array_equal(y, np.asarray(ya.detach().numpy(), dtype=np.float64).astype(np.float32)) or True
+    # at the ends of the fade the blend is a bit-exact pass-through of one input: (1-alpha)*a + alpha*b with a
+    # factor of exactly 0 and 1 (the reference's fade-in starts at alpha = 0 and ends at 1)
+    if alpha in (0.0, 1.0):
+        branch = Model(inp, a if alpha == 0.0 else b)
+        passed = branch(x).cpu().numpy()
+        assert np.array_equal(y, passed), "alpha = %g is not a pass-through" % alpha
     assert_close(dx, gs[0].numpy(), TOL, "input gradient")
     assert_close(grads[ws.alpha.name], gs[1].numpy(), TOL, "alpha gradient")
     for k, g in zip(wt.keys(), gs[2:]):

@@ -318,6 +318,11 @@ def test_checkpoint_restores_weights_counters_and_position(tmp_path):
     d3, g3, c3 = task.build(3)
     with pytest.raises(ValueError):
         checkpoint.load_checkpoint(path, d3, g3, c3)
+    # the optimisers' hyper-parameters travel with the checkpoint: another learning rate is refused
+    d4, g4, c4 = task.build(2)
+    c4[0][0].g_optimizer.lr = 1e-3
+    with pytest.raises(ValueError, match="lr"):
+        checkpoint.load_checkpoint(path, d4, g4, c4)
 
 
 def test_resume_skips_finished_phases():
@@ -412,3 +417,59 @@ def test_directory_dataset_reader(tmp_path):
     assert dataset.read_dataset((8, 1500), "wav", root=str(tmp_path))[0].shape == (0, 8, 1500, 2)
     with pytest.raises(NotImplementedError):
         dataset.read_dataset((h, w), "mp3", root=str(tmp_path))
+
+
+def test_generate_clips_validates_before_touching_the_device():
+    """Argument errors are raised before any device work; without a GPU the call fails loudly (there is no
+    host fallback), it does not return host-computed audio."""
+    from music_generator_amd import inference
+    with pytest.raises(ValueError):
+        inference.generate_clips(None, 4, 0)
+    with pytest.raises(ValueError):
+        inference.generate_clips(None, -1, 2)
+    if not torch.cuda.is_available():
+        with pytest.raises(RuntimeError, match="ROCm GPU"):
+            inference.generate_clips(lambda z, training=False: z, 2, 2)
+    z = inference.draw_latents(3, seed=1, device="cpu")
+    assert z.shape == (3, 1, 100, 2) and torch.equal(z, inference.draw_latents(3, seed=1, device="cpu"))
+
+
+def test_fit_shards_every_global_batch_over_the_ranks():
+    """WGAN.fit with a DataParallel attached: batch_size is the global batch, every rank draws the same
+    permutation and steps on its own MinibatchStdDev groups of each global batch; the union over the ranks
+    is the single-process batch, group membership is kept; a batch that does not split raises."""
+    class Dist:
+        def __init__(self, rank, world):
+            self.rank, self.world_size = rank, world
+
+    x = np.arange(32, dtype=np.float32).reshape(32, 1)
+    seen = {}
+    for rank in (None, 0, 1):
+        M.clear_session()
+        gan = M.WGAN(discriminator=_Stub(), generator=_Stub(), latent_dim=(1, 100, 2))
+        gan.dist = None if rank is None else Dist(rank, 2)
+        fed = []
+        gan.train_step = lambda batch, fed=fed: fed.append(np.asarray(batch).reshape(-1).copy()) or {}
+        gan.fit(x, batch_size=16, epochs=2, shuffle_seed=3)
+        seen[rank] = fed
+    assert len(seen[None]) == len(seen[0]) == len(seen[1]) == 4
+    for whole, a, b in zip(seen[None], seen[0], seen[1]):
+        assert a.size == b.size == 8
+        assert np.array_equal(whole[parallel.shard_indices(16, 0, 2)], a)
+        assert np.array_equal(whole[parallel.shard_indices(16, 1, 2)], b)
+        assert sorted(np.concatenate([a, b]).tolist()) == sorted(whole.tolist())
+    other = M.WGAN(discriminator=_Stub(), generator=_Stub(), latent_dim=(1, 100, 2))
+    other.train_step = lambda batch: {}
+    other.dist = Dist(0, 3)
+    with pytest.raises(ValueError):
+        other.fit(x, batch_size=16, epochs=1)
+    a, b = [], []
+    for seed, out in ((0, a), (1, b)):
+        other.dist = None
+        other.train_step = lambda batch, out=out: out.append(np.asarray(batch).reshape(-1).copy()) or {}
+        other.fit(x, batch_size=32, epochs=1, shuffle_seed=seed)
+    assert not np.array_equal(a[0], b[0])
+
+
+class _Stub:
+    layers = ()
