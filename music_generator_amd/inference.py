@@ -65,9 +65,18 @@ class ChecksumSink:
         self.clips = 0
 
     def __call__(self, first: int, audio: torch.Tensor):
-        a = audio.reshape(audio.shape[0], -1)
-        d = a.double()
-        self._rows.append(torch.stack([d.sum(1), (d * d).sum(1), a.abs().amax(1).double()], dim=1))
+        m = audio.shape[0]
+        size = audio.numel() // max(m, 1)
+        # three single-pass reductions, accumulated in float64 without a float64 copy of the chunk.  A clip is
+        # reduced in `parts` pieces first: a handful of rows of 25 M elements would leave most of the GPU idle.
+        parts = 1
+        while parts < 4096 and size % (2 * parts) == 0:
+            parts *= 2
+        a = audio.reshape(m * parts, size // parts)
+        norm = torch.linalg.vector_norm(a, ord=2, dim=1, dtype=torch.float64).view(m, parts)
+        peak = torch.linalg.vector_norm(a, ord=float("inf"), dim=1).view(m, parts)
+        total = a.sum(1, dtype=torch.float64).view(m, parts)
+        self._rows.append(torch.stack([total.sum(1), (norm * norm).sum(1), peak.amax(1).double()], dim=1))
         self.clips += audio.shape[0]
 
     def result(self) -> np.ndarray:
