@@ -120,9 +120,13 @@ def cpu_baseline(stage, fade, sample_batch, n_blocks, timed=3):
                                                           timed, dt)}
 
 
-def measured_traffic(kernel, stage, fade, batch):
+def _norm(name):
+    return name.replace(", ", ",")
+
+
+def measured_traffic(kernel, workload):
     """HBM bytes per launch of `kernel` from the committed PMC passes (profiles/pmc_traffic.json:
-    2 x FETCH_SIZE + WRITE_SIZE of separate rocprofv3 --pmc runs of this same command), or None
+    2 x FETCH_SIZE + WRITE_SIZE of separate rocprofv3 --pmc runs of the same workload), or None
     when no pass for this workload and kernel is on file."""
     path = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     try:
@@ -130,13 +134,28 @@ def measured_traffic(kernel, stage, fade, batch):
             table = json.load(f)
     except (OSError, ValueError):
         return None
-    wl = table.get("stage%d_%s_b%d" % (stage, "fade" if fade else "straight", batch), {})
+    wl = table.get(workload, {})
     entry = wl.get(kernel)
     if entry:
         return entry["hbm_bytes_per_launch"]
     inst = [e for k, e in wl.items() if isinstance(e, dict) and k.startswith(kernel + "<")]
     n = sum(e["launches_per_step"] for e in inst)
     return round(sum(e["hbm_bytes_per_launch"] * e["launches_per_step"] for e in inst) / n) if n else None
+
+
+def measured_mfma_busy(kernel, digest):
+    """Matrix-unit occupancy of `kernel` from the committed SQ counter pass of the same workload
+    (profiles/<digest>_digest.json: SQ_VALU_MFMA_BUSY_CYCLES / (launch duration x 2.4 GHz x 1024 SIMDs),
+    launch-weighted over the kernel's template instances), or None."""
+    try:
+        with open(os.path.join(ROOT, "profiles", digest + "_digest.json")) as f:
+            rows = json.load(f)["kernels"]
+    except (OSError, ValueError, KeyError):
+        return None
+    inst = [r for r in rows if "mfma_busy_frac" in r and (_norm(r["kernel"]) == kernel or
+                                                           _norm(r["kernel"]).startswith(kernel + "<"))]
+    t = sum(r["calls"] * r["avg_us"] for r in inst)
+    return round(sum(r["mfma_busy_frac"] * r["calls"] * r["avg_us"] for r in inst) / t, 4) if t else None
 
 
 def build_gan(M, stage, fade, precision, micro_batch=None, side_budget_gib=0.0):
@@ -224,7 +243,10 @@ def c3_run(torch, M, ops, batch):
     ops.PROFILER = None
     progress("c3: %.1f s per step, %.2f samples/s" % (dt, batch / dt))
     summ = prof.summary()
-    _, roof = roofline_of(summ, 1, dt * 1e3, BF16_MFMA_PEAK_TFLOPS)
+    key, roof = roofline_of(summ, 1, dt * 1e3, BF16_MFMA_PEAK_TFLOPS)
+    # counter passes of the same step at batch 16 (the launches are those of the batch-256 step)
+    roof["traffic"] = measured_traffic(key, "stage6_fade_mb4_bf16")
+    roof["mfma_busy_frac_sq_counters"] = measured_mfma_busy(key, "r2_c3")
     top = sorted(summ.items(), key=lambda kv: -kv[1][1])[:8]
     out = {"workload": "stage-6 (256x48000) fade-in G+D train step, batch %d (micro-batches of 4), bf16 storage / "
                        "bf16 MFMA / f32 accumulation, f32 master weights" % batch,
@@ -405,7 +427,12 @@ def main():
                           for k, v in summ.items() if v[2] == 0.0 and v[1] > 0}
         key, roof = roofline_of(summ, args.steps, ms_per_step,
                                 BF16_MFMA_PEAK_TFLOPS if args.precision == "bfloat16" else F32_MFMA_PEAK_TFLOPS)
-        roof["traffic"] = measured_traffic(key, stage, fade, args.batch)
+        wl = "stage%d_%s_b%d%s" % (stage, "fade" if fade else "straight", args.batch,
+                                   "_bf16" if args.precision == "bfloat16" else "")
+        roof["traffic"] = measured_traffic(key, wl)
+        if (stage, fade, args.batch) == (3, True, 64):
+            roof["mfma_busy_frac_sq_counters"] = measured_mfma_busy(key, "r2_c2bf16" if args.precision == "bfloat16"
+                                                                    else "r2_c2")
         if key.startswith("wino3_"):
             # the kernel's algorithm is Winograd F(2x2,3x3): `achieved` counts the multiply-adds it executes
             # (16 per 2x2 patch and channel pair); the same launches as a rate of direct-convolution FLOPs:

@@ -2,6 +2,7 @@
 #pragma once
 #include <hip/hip_runtime.h>
 #include <stdint.h>
+#include <atomic>
 
 #define MGX_OK 0
 #define MGX_ERR_ARG 1
@@ -72,4 +73,18 @@ __device__ __forceinline__ void tanh_sech2(float x, float& t, float& s) {
 
 static inline int mgx_launch_status() {
     return hipGetLastError() == hipSuccess ? MGX_OK : MGX_ERR_LAUNCH;
+}
+
+// More than 64 KiB of dynamic LDS must be allowed per kernel function AND per device.  `done` (one
+// static per call site) holds one bit per device already served; two threads racing on a first call
+// both set the attribute, which is harmless.  A failure is left pending in the runtime's last-error
+// slot (and the launch that follows fails as well), so mgx_launch_status() reports it.
+template <typename K>
+static inline void mgx_allow_dynamic_lds(K kernel, int bytes, std::atomic<uint64_t>& done) {
+    int dev = 0;
+    if (hipGetDevice(&dev) != hipSuccess) return;
+    const uint64_t bit = 1ull << (dev & 63);
+    if (done.load(std::memory_order_acquire) & bit) return;
+    if (hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, bytes) == hipSuccess)
+        done.fetch_or(bit, std::memory_order_release);
 }

@@ -399,8 +399,10 @@ int launch_pointwise_to2(const mgx_conv_desc& d, const float* x, const float* xm
 // route 2 also covers the 1x1 convolutions to 2 output channels (any input multiplier)
 bool mgx_pointwise_to2_applicable(const mgx_conv_desc& d) { return pointwise_to2_applicable(d); }
 
-// The Winograd forward kernel is used unless the environment says MGX_WINOGRAD=0 (read once).
-// read at every call: a process can compare the two kernels on the same operands
+// The Winograd kernels are used unless the environment says MGX_WINOGRAD=0.  The variable is read at
+// every call (forward, data-gradient, weight-gradient workspace query and launch alike), so a process
+// can compare the two kernel families on the same operands by changing it between calls; a caller that
+// changes it between a workspace query and the launch it sized must query again.
 bool mgx_wconv_enabled() {
     const char* e = getenv("MGX_WINOGRAD");
     return !(e && e[0] == '0');

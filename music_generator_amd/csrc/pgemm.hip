@@ -108,12 +108,8 @@ int launch_kn(const mgx_conv_desc& d, const float* x, const float* w, const floa
     const bool wt = d.wsk == 1;
 #define MGX_PG(WW)                                                                                                   \
     do {                                                                                                             \
-        static bool allowed = false;                                                                                 \
-        if (!allowed) {                                                                                              \
-            (void)hipFuncSetAttribute((const void*)pgemm_kernel<KS, NT, WW>,                                         \
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, lds);                              \
-            allowed = true;                                                                                          \
-        }                                                                                                            \
+        static std::atomic<uint64_t> allowed{0};                                                                     \
+        mgx_allow_dynamic_lds(pgemm_kernel<KS, NT, WW>, lds, allowed);                                               \
         hipLaunchKernelGGL((pgemm_kernel<KS, NT, WW>), dim3(grid), dim3(256), lds, st, x, w, bias, y, R, (long)d.wsk, \
                            (long)d.wsn, ntiles);                                                                     \
     } while (0)

@@ -296,12 +296,8 @@ void launch3(const mgx_conv_desc& d, const float* x, const float* xmul, const fl
     // more than 64 KiB of dynamic LDS must be allowed per kernel function
 #define MGX_T3(WW, MM)                                                                                               \
     do {                                                                                                             \
-        static bool allowed = false;                                                                                 \
-        if (!allowed) {                                                                                              \
-            (void)hipFuncSetAttribute((const void*)tconv3_kernel<KH, KW, WW, MM, TH>,                                      \
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, lds);                              \
-            allowed = true;                                                                                          \
-        }                                                                                                            \
+        static std::atomic<uint64_t> allowed{0};                                                                     \
+        mgx_allow_dynamic_lds(tconv3_kernel<KH, KW, WW, MM, TH>, lds, allowed);                                      \
         hipLaunchKernelGGL((tconv3_kernel<KH, KW, WW, MM, TH>), dim3(grid), dim3(512), lds, st, d, x, xmul, w, bias, y,   \
                            dact, ntiles, tiles_h, tiles_w, gin_w, scat);                                             \
     } while (0)

@@ -499,12 +499,8 @@ int mgx_wconv_launch(const mgx_conv_desc& d, const float* x, const float* xmul, 
     const unsigned grid = (unsigned)(ntiles < 256 ? ntiles : 256);
 #define MGX_W3(MM, SS, UU, OO, Y, WP, BP)                                                                           \
     do {                                                                                                            \
-        static bool allowed = false;                                                                                \
-        if (!allowed) {                                                                                             \
-            (void)hipFuncSetAttribute((const void*)wino3_kernel<MM, SS, UU, OO>,                                    \
-                                      hipFuncAttributeMaxDynamicSharedMemorySize, W_LDS_BYTES);                     \
-            allowed = true;                                                                                         \
-        }                                                                                                           \
+        static std::atomic<uint64_t> allowed{0};                                                                    \
+        mgx_allow_dynamic_lds(wino3_kernel<MM, SS, UU, OO>, W_LDS_BYTES, allowed);                                  \
         hipLaunchKernelGGL((wino3_kernel<MM, SS, UU, OO>), dim3(grid), dim3(256), W_LDS_BYTES, st, d, x, xmul, WP,  \
                            BP, Y, dact, ntiles, tiles_h, tiles_w);                                                  \
     } while (0)

@@ -305,14 +305,9 @@ int mgx_wwgrad_launch(const mgx_conv_desc& d, const float* x, const float* dy, c
     const int tiles_h = d.hin / GTH, tiles_w = (d.win + GTW - 1) / GTW;
     const long ntiles = (long)d.nimg * tiles_h * tiles_w;
     dim3 grid(wgrid(ntiles), d.cin / 32), block(256);
-    static bool allowed = false;
-    if (!allowed) {
-        (void)hipFuncSetAttribute((const void*)wino3_wgrad_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  G_LDS_BYTES);
-        (void)hipFuncSetAttribute((const void*)wino3_wgrad_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                  G_LDS_BYTES);
-        allowed = true;
-    }
+    static std::atomic<uint64_t> allowed_mul{0}, allowed_plain{0};
+    mgx_allow_dynamic_lds(wino3_wgrad_kernel<true>, G_LDS_BYTES, allowed_mul);
+    mgx_allow_dynamic_lds(wino3_wgrad_kernel<false>, G_LDS_BYTES, allowed_plain);
     if (dymul)
         hipLaunchKernelGGL((wino3_wgrad_kernel<true>), grid, block, G_LDS_BYTES, st, d, x, dy, dymul, partial, bpartial,
                            ntiles, tiles_h, tiles_w);
