@@ -481,3 +481,82 @@ def test_bf16_generator_backward_matches_oracle(stage, twin, budget):
     for k, err in errs.items():
         tol = 2e-1 if k.endswith("/alpha") else (5e-2 if got[k].size < 64 else 3e-2)
         assert err <= tol, "%s: rel-L2 %.3e" % (k, err)
+
+
+def _fresh_gan(stage, micro_batch, budget_gib=None, seed=11):
+    from music_generator_amd.graph import FusedGroup
+    M.clear_session()
+    d = M.define_discriminator(stage + 1)
+    g = M.define_generator(stage + 1)
+    gan = M.define_composite(d, g, (1, 100, 2))[stage][1]
+    gan.micro_batch = micro_batch
+    FusedGroup.side_budget_bytes = int(budget_gib * 2 ** 30) if budget_gib else None
+    gan.set_train_steps(9)
+    gan.actual_step = 3
+    gan.seed(seed)
+    return gan
+
+
+def test_bf16_upper_stage_micro_batches_equal_whole_batch(bf16_precision):
+    """Stage 5 (128 x 24000), batch 8, bf16: the step in micro-batches of one MinibatchStdDev group against the
+    whole batch at once.  Every sample's bf16 arithmetic is the same in both; only the float32 order in
+    which per-micro-batch gradient sums are added differs: metrics abs 1e-5, discriminator gradients rel-L2
+    5e-5 (5e-4 alpha), generator gradients 2e-2 (taken after the sign-like first Adam step of D)."""
+    from music_generator_amd.graph import FusedGroup
+    stage, n = 5, 8
+    gen = torch.Generator(device="cuda")
+    gen.manual_seed(3)
+    real = torch.rand((n, 4 << stage, 750 << stage, 2), device="cuda", generator=gen) * 2 - 1
+    runs = []
+    try:
+        for mb in (None, 4):
+            gan = _fresh_gan(stage, mb)     # initial values are a function of the variable names: both builds equal
+            m = {k: float(v) for k, v in gan.train_step(real).items()}
+            grads = {v.name: v.grad.cpu().numpy().copy() for model in (gan.discriminator, gan.generator)
+                     for v in model.trainable_variables}
+            d_names = {v.name for v in gan.discriminator.trainable_variables}
+            runs.append((m, grads))
+            del gan
+            torch.cuda.empty_cache()
+    finally:
+        FusedGroup.side_budget_bytes = None
+    (m0, g0), (m1, g1) = runs
+    for k in m0:
+        assert np.isfinite(m0[k]) and abs(m0[k] - m1[k]) < 1e-5, (k, m0[k], m1[k])
+    for k, v in g0.items():
+        assert np.isfinite(g1[k]).all(), k
+        if np.abs(v).max() < 1e-12:
+            continue
+        tol = (5e-4 if k.endswith("/alpha") else 5e-5) if k in d_names else 2e-2
+        assert rel_l2(g1[k], v) < tol, "%s: %.3e" % (k, rel_l2(g1[k], v))
+
+
+def test_bf16_full_resolution_step_properties(bf16_precision):
+    """Stage 6 (256 x 48000), batch 8 in micro-batches of 4, generator tape bounded to 8 GiB (re-computing
+    backward), bf16: the configuration of the full-resolution bench step at a batch pytest can afford.
+    Size-independent properties: all six metrics and every gradient finite and not all zero; the reported
+    distance is |mean fake logit - mean real logit| (models.py:469-472); generated clips obey the
+    LayerNormalization identity (per-clip mean 0, mean square just under 1 for gamma = 1, beta = 0)."""
+    from music_generator_amd.graph import FusedGroup
+    from music_generator_amd.inference import ChecksumSink, generate_clips
+    stage, n = 6, 8
+    try:
+        gan = _fresh_gan(stage, 4, 8.0)
+        chk = ChecksumSink()
+        generate_clips(gan.generator, 2, 2, chk, seed=1)
+        res = chk.result()
+        size = 256 * 48000 * 2
+        assert np.abs(res[:, 0] / size).max() < 1e-4 and ((res[:, 1] / size) < 1 + 1e-4).all()
+        gen = torch.Generator(device="cuda")
+        gen.manual_seed(4)
+        real = torch.rand((n, 256, 48000, 2), device="cuda", generator=gen) * 2 - 1
+        m = {k: float(v) for k, v in gan.train_step(real).items()}
+        assert all(np.isfinite(v) for v in m.values()), m
+        for i in ("0", "1"):
+            assert abs(m["delta_" + i] - abs(m["cu_" + i] - m["ci_" + i])) < 1e-5, m
+        for model in (gan.discriminator, gan.generator):
+            flat = model.bind_grads(0)
+            assert bool(torch.isfinite(flat).all()) and float(flat.abs().max()) > 0.0
+        assert gan.actual_step == 4 and gan.d_optimizer.iterations == 1 and gan.g_optimizer.iterations == 1
+    finally:
+        FusedGroup.side_budget_bytes = None
