@@ -28,10 +28,21 @@ __global__ __launch_bounds__(kBlock) void ln_partial_kernel(const float* __restr
     if (end > e) end = e;
     const float* src = x + img * e;
     double s = 0.0, q = 0.0;
-    for (long i = beg + threadIdx.x; i < end; i += kBlock) {
-        const double v = (double)src[i];
-        s += v;
-        q += v * v;
+    if ((e & 3) == 0) {
+        // 16-byte loads (chunk and e are multiples of 4, the sample base is 16-byte aligned); the four values
+        // of a load are summed in float32 pairs, the running sums are double
+        const float4* s4 = (const float4*)src;
+        for (long i = beg / 4 + threadIdx.x; i < end / 4; i += kBlock) {
+            const float4 v = s4[i];
+            s += (double)((v.x + v.y) + (v.z + v.w));
+            q += (double)(v.x * v.x + v.y * v.y) + (double)(v.z * v.z + v.w * v.w);
+        }
+    } else {
+        for (long i = beg + threadIdx.x; i < end; i += kBlock) {
+            const double v = (double)src[i];
+            s += v;
+            q += v * v;
+        }
     }
     const double ts = block_sum256_d(s, red);
     const double tq = block_sum256_d(q, red);
@@ -68,6 +79,15 @@ __global__ __launch_bounds__(kBlock) void ln_apply_kernel(const float* __restric
     const float mean = stats[img * 2], rstd = stats[img * 2 + 1];
     const float* src = x + img * e;
     float* dst = y + img * e;
+    if ((e & 3) == 0) {
+        const long e4 = e / 4;
+        for (long i = (long)blockIdx.x * kBlock + threadIdx.x; i < e4; i += (long)gridDim.x * kBlock) {
+            const float4 v = ((const float4*)src)[i], g = ((const float4*)gamma)[i], b = ((const float4*)beta)[i];
+            ((float4*)dst)[i] = make_float4((v.x - mean) * rstd * g.x + b.x, (v.y - mean) * rstd * g.y + b.y,
+                                            (v.z - mean) * rstd * g.z + b.z, (v.w - mean) * rstd * g.w + b.w);
+        }
+        return;
+    }
     const long e2 = e / 2;  // e is always even (2 channels innermost)
     for (long i = (long)blockIdx.x * kBlock + threadIdx.x; i < e2; i += (long)gridDim.x * kBlock) {
         const float2 v = ((const float2*)src)[i], g = ((const float2*)gamma)[i], b = ((const float2*)beta)[i];
@@ -94,11 +114,21 @@ __global__ __launch_bounds__(kBlock) void ln_bwd_partial_kernel(const float* __r
     const float* g = dy + img * e;
     const float* src = x + img * e;
     double s1 = 0.0, s2 = 0.0;
-    for (long i = beg + threadIdx.x; i < end; i += kBlock) {
-        const float gg = g[i] * gamma[i];
-        const float xh = (src[i] - mean) * rstd;
-        s1 += (double)gg;
-        s2 += (double)gg * (double)xh;
+    if ((e & 3) == 0) {
+        for (long i = beg / 4 + threadIdx.x; i < end / 4; i += kBlock) {
+            const float4 d = ((const float4*)g)[i], gm = ((const float4*)gamma)[i], v = ((const float4*)src)[i];
+            const float g0 = d.x * gm.x, g1 = d.y * gm.y, g2 = d.z * gm.z, g3 = d.w * gm.w;
+            s1 += (double)((g0 + g1) + (g2 + g3));
+            s2 += (double)(g0 * ((v.x - mean) * rstd) + g1 * ((v.y - mean) * rstd)) +
+                  (double)(g2 * ((v.z - mean) * rstd) + g3 * ((v.w - mean) * rstd));
+        }
+    } else {
+        for (long i = beg + threadIdx.x; i < end; i += kBlock) {
+            const float gg = g[i] * gamma[i];
+            const float xh = (src[i] - mean) * rstd;
+            s1 += (double)gg;
+            s2 += (double)gg * (double)xh;
+        }
     }
     const double t1 = block_sum256_d(s1, red);
     const double t2 = block_sum256_d(s2, red);
@@ -149,6 +179,47 @@ __global__ __launch_bounds__(kBlock) void ln_bwd_apply_kernel(const float* __res
         }
         if (dgamma) dgamma[i] += dg;
         if (dbeta) dbeta[i] += db;
+    }
+}
+
+// the same with four element positions per thread (e a multiple of 4)
+__global__ __launch_bounds__(kBlock) void ln_bwd_apply4_kernel(const float4* __restrict__ dy, const float4* __restrict__ x,
+                                                               const float4* __restrict__ gamma,
+                                                               const float* __restrict__ stats,
+                                                               const float* __restrict__ sums, float4* __restrict__ dx,
+                                                               int acc_x, float4* __restrict__ dgamma,
+                                                               float4* __restrict__ dbeta, long nimg, long e4) {
+    for (long i = (long)blockIdx.x * kBlock + threadIdx.x; i < e4; i += (long)gridDim.x * kBlock) {
+        const float4 gm = gamma[i];
+        float4 dg = make_float4(0.f, 0.f, 0.f, 0.f), db = dg;
+        for (long n = 0; n < nimg; ++n) {
+            const float mean = stats[n * 2], rstd = stats[n * 2 + 1];
+            const float m1 = sums[n * 2], m2 = sums[n * 2 + 1];
+            const long o = n * e4 + i;
+            const float4 g = dy[o], v = x[o];
+            const float4 xh = make_float4((v.x - mean) * rstd, (v.y - mean) * rstd, (v.z - mean) * rstd, (v.w - mean) * rstd);
+            dg.x += g.x * xh.x; dg.y += g.y * xh.y; dg.z += g.z * xh.z; dg.w += g.w * xh.w;
+            db.x += g.x; db.y += g.y; db.z += g.z; db.w += g.w;
+            if (dx) {
+                float4 r = make_float4(rstd * (g.x * gm.x - m1 - xh.x * m2), rstd * (g.y * gm.y - m1 - xh.y * m2),
+                                       rstd * (g.z * gm.z - m1 - xh.z * m2), rstd * (g.w * gm.w - m1 - xh.w * m2));
+                if (acc_x) {
+                    const float4 p = dx[o];
+                    r.x += p.x; r.y += p.y; r.z += p.z; r.w += p.w;
+                }
+                dx[o] = r;
+            }
+        }
+        if (dgamma) {
+            float4 p = dgamma[i];
+            p.x += dg.x; p.y += dg.y; p.z += dg.z; p.w += dg.w;
+            dgamma[i] = p;
+        }
+        if (dbeta) {
+            float4 p = dbeta[i];
+            p.x += db.x; p.y += db.y; p.z += db.z; p.w += db.w;
+            dbeta[i] = p;
+        }
     }
 }
 
@@ -237,6 +308,124 @@ __global__ __launch_bounds__(kBlock) void mb_bwd_kernel(const float* __restrict_
             const long smp = k * m_groups + m;
             dx[smp * e + i] = dy[smp * (e + row) + i] + ds * (v[k] - mean) * inv_std;
         }
+    }
+}
+
+// ---- 16-byte forms (e and the appended row are multiples of 4 floats): two launches per direction ----
+// grid (B, M): copies the group's members into y while summing sqrt(var + 1e-8) over the chunk.
+__global__ __launch_bounds__(kBlock) void mb_fwd4_kernel(const float4* __restrict__ x, float4* __restrict__ y,
+                                                         double* __restrict__ part, long e4, long ye4, int g,
+                                                         long m_groups, long bps) {
+    __shared__ double red[4];
+    const long m = blockIdx.y, b = blockIdx.x;
+    const long chunk = (e4 + bps - 1) / bps;
+    const long beg = b * chunk;
+    long end = beg + chunk;
+    if (end > e4) end = e4;
+    const float inv_g = 1.0f / (float)g;
+    double s = 0.0;
+    for (long i = beg + threadIdx.x; i < end; i += kBlock) {
+        float4 v[4];
+        float4 mean = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (k < g) {
+                v[k] = x[(k * m_groups + m) * e4 + i];
+                mean.x += v[k].x; mean.y += v[k].y; mean.z += v[k].z; mean.w += v[k].w;
+            }
+        mean.x *= inv_g; mean.y *= inv_g; mean.z *= inv_g; mean.w *= inv_g;
+        float4 var = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (k < g) {
+                const float dx = v[k].x - mean.x, dy = v[k].y - mean.y, dz = v[k].z - mean.z, dw = v[k].w - mean.w;
+                var.x += dx * dx; var.y += dy * dy; var.z += dz * dz; var.w += dw * dw;
+                y[(k * m_groups + m) * ye4 + i] = v[k];
+            }
+        s += (double)((sqrtf(var.x * inv_g + 1e-8f) + sqrtf(var.y * inv_g + 1e-8f)) +
+                      (sqrtf(var.z * inv_g + 1e-8f) + sqrtf(var.w * inv_g + 1e-8f)));
+    }
+    const double t = block_sum256_d(s, red);
+    if (threadIdx.x == 0) part[m * bps + b] = t;
+}
+
+// grid (N): the statistic of the sample's group from the partial sums, written to the appended row
+__global__ __launch_bounds__(kBlock) void mb_row4_kernel(const double* __restrict__ part, float* __restrict__ stat,
+                                                         float4* __restrict__ y, long e, long e4, long ye4, long row4,
+                                                         long m_groups, long bps) {
+    __shared__ double red[4];
+    __shared__ float sval;
+    const long i = blockIdx.x, m = i % m_groups;
+    double s = 0.0;
+    for (long b = threadIdx.x; b < bps; b += kBlock) s += part[m * bps + b];
+    const double t = block_sum256_d(s, red);
+    if (threadIdx.x == 0) {
+        sval = (float)(t / (double)e);
+        if (i < m_groups) stat[m] = sval;
+    }
+    __syncthreads();
+    const float v = sval;
+    const float4 v4 = make_float4(v, v, v, v);
+    float4* dst = y + i * ye4 + e4;
+    for (long j = threadIdx.x; j < row4; j += kBlock) dst[j] = v4;
+}
+
+// grid (M, 4): partial sums of dy over the appended rows of the group's members
+__global__ __launch_bounds__(kBlock) void mb_dstat4_kernel(const float4* __restrict__ dy, double* __restrict__ dpart,
+                                                           long e4, long ye4, long row4, int g, long m_groups) {
+    __shared__ double red[4];
+    const long m = blockIdx.x;
+    const int k = blockIdx.y;
+    double s = 0.0;
+    if (k < g) {
+        const float4* src = dy + (k * m_groups + m) * ye4 + e4;
+        for (long j = threadIdx.x; j < row4; j += kBlock) {
+            const float4 v = src[j];
+            s += (double)((v.x + v.y) + (v.z + v.w));
+        }
+    }
+    const double t = block_sum256_d(s, red);
+    if (threadIdx.x == 0) dpart[m * 4 + k] = t;
+}
+
+__global__ __launch_bounds__(kBlock) void mb_bwd4_kernel(const float4* __restrict__ dy, const float4* __restrict__ x,
+                                                         const double* __restrict__ dpart, float4* __restrict__ dx,
+                                                         long e, long e4, long ye4, int g, long m_groups, long bps) {
+    const long m = blockIdx.y, b = blockIdx.x;
+    const long chunk = (e4 + bps - 1) / bps;
+    const long beg = b * chunk;
+    long end = beg + chunk;
+    if (end > e4) end = e4;
+    const float dstat = (float)((dpart[m * 4] + dpart[m * 4 + 1]) + (dpart[m * 4 + 2] + dpart[m * 4 + 3]));
+    const float ds = dstat / ((float)g * (float)e);
+    const float inv_g = 1.0f / (float)g;
+    for (long i = beg + threadIdx.x; i < end; i += kBlock) {
+        float4 v[4];
+        float4 mean = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (k < g) {
+                v[k] = x[(k * m_groups + m) * e4 + i];
+                mean.x += v[k].x; mean.y += v[k].y; mean.z += v[k].z; mean.w += v[k].w;
+            }
+        mean.x *= inv_g; mean.y *= inv_g; mean.z *= inv_g; mean.w *= inv_g;
+        float4 var = make_float4(0.f, 0.f, 0.f, 0.f);
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (k < g) {
+                const float ax = v[k].x - mean.x, ay = v[k].y - mean.y, az = v[k].z - mean.z, aw = v[k].w - mean.w;
+                var.x += ax * ax; var.y += ay * ay; var.z += az * az; var.w += aw * aw;
+            }
+        const float4 is = make_float4(ds / sqrtf(var.x * inv_g + 1e-8f), ds / sqrtf(var.y * inv_g + 1e-8f),
+                                      ds / sqrtf(var.z * inv_g + 1e-8f), ds / sqrtf(var.w * inv_g + 1e-8f));
+#pragma unroll
+        for (int k = 0; k < 4; ++k)
+            if (k < g) {
+                const long smp = k * m_groups + m;
+                const float4 d = dy[smp * ye4 + i];
+                dx[smp * e4 + i] = make_float4(d.x + (v[k].x - mean.x) * is.x, d.y + (v[k].y - mean.y) * is.y,
+                                               d.z + (v[k].z - mean.z) * is.z, d.w + (v[k].w - mean.w) * is.w);
+            }
     }
 }
 
@@ -426,6 +615,14 @@ extern "C" int mgx_layernorm_bwd(const float* dy, const float* x, const float* g
     hipLaunchKernelGGL(ln_bwd_partial_kernel, dim3((unsigned)bps, (unsigned)nimg), dim3(kBlock), 0, st, dy, x, gamma,
                        stats, part, (long)e, bps);
     hipLaunchKernelGGL(ln_bwd_sums_kernel, dim3((unsigned)nimg), dim3(64), 0, st, part, sums, (long)e, bps);
+    if ((e & 3) == 0) {
+        long g4 = (e / 4 + kBlock - 1) / kBlock;
+        if (g4 > 8192) g4 = 8192;
+        hipLaunchKernelGGL(ln_bwd_apply4_kernel, dim3((unsigned)g4), dim3(kBlock), 0, st, (const float4*)dy,
+                           (const float4*)x, (const float4*)gamma, stats, sums, (float4*)dx, acc_x, (float4*)dgamma,
+                           (float4*)dbeta, (long)nimg, (long)(e / 4));
+        return mgx_launch_status();
+    }
     long gx = (e + kBlock - 1) / kBlock;
     if (gx > 8192) gx = 8192;
     hipLaunchKernelGGL(ln_bwd_apply_kernel, dim3((unsigned)gx), dim3(kBlock), 0, st, dy, x, gamma, stats, sums, dx, acc_x,
@@ -437,7 +634,8 @@ extern "C" int64_t mgx_mbstd_workspace(int64_t n, int64_t e) {
     if (n <= 0 || e <= 0) return -1;
     const long g = n < 4 ? n : 4;
     const long m = n / g;
-    return m * mb_blocks(e) * (int64_t)sizeof(double) + m * (int64_t)sizeof(float);
+    const long parts = mb_blocks(e) > 4 ? mb_blocks(e) : 4;       // forward: blocks per group; backward: 4 row sums
+    return m * parts * (int64_t)sizeof(double) + m * (int64_t)sizeof(float);
 }
 
 extern "C" int mgx_mbstd_fwd(const float* x, float* y, float* stat, int64_t n, int h, int w, int c, void* workspace,
@@ -452,6 +650,13 @@ extern "C" int mgx_mbstd_fwd(const float* x, float* y, float* stat, int64_t n, i
     hipStream_t st = (hipStream_t)stream;
     const long bps = mb_blocks(e);
     double* part = (double*)workspace;
+    if ((e & 3) == 0 && (row & 3) == 0) {
+        hipLaunchKernelGGL(mb_fwd4_kernel, dim3((unsigned)bps, (unsigned)m), dim3(kBlock), 0, st, (const float4*)x,
+                           (float4*)y, part, e / 4, (e + row) / 4, g, m, bps);
+        hipLaunchKernelGGL(mb_row4_kernel, dim3((unsigned)n), dim3(kBlock), 0, st, part, stat, (float4*)y, e, e / 4,
+                           (e + row) / 4, row / 4, m, bps);
+        return mgx_launch_status();
+    }
     hipLaunchKernelGGL(mb_partial_kernel, dim3((unsigned)bps, (unsigned)m), dim3(kBlock), 0, st, x, part, e, g, m, bps);
     hipLaunchKernelGGL(mb_stat_kernel, dim3((unsigned)m), dim3(64), 0, st, part, stat, e, bps);
     long gx = (e + row + kBlock - 1) / kBlock;
@@ -471,7 +676,15 @@ extern "C" int mgx_mbstd_bwd(const float* dy, const float* x, float* dx, int64_t
     if (workspace_bytes < mgx_mbstd_workspace(n, e)) return MGX_ERR_WORKSPACE;
     hipStream_t st = (hipStream_t)stream;
     const long bps = mb_blocks(e);
-    float* dstat = (float*)((double*)workspace + m * bps);
+    if ((e & 3) == 0 && (row & 3) == 0) {
+        double* dpart = (double*)workspace;
+        hipLaunchKernelGGL(mb_dstat4_kernel, dim3((unsigned)m, 4), dim3(kBlock), 0, st, (const float4*)dy, dpart, e / 4,
+                           (e + row) / 4, row / 4, g, m);
+        hipLaunchKernelGGL(mb_bwd4_kernel, dim3((unsigned)bps, (unsigned)m), dim3(kBlock), 0, st, (const float4*)dy,
+                           (const float4*)x, dpart, (float4*)dx, e, e / 4, (e + row) / 4, g, m, bps);
+        return mgx_launch_status();
+    }
+    float* dstat = (float*)((double*)workspace + m * (bps > 4 ? bps : 4));
     hipLaunchKernelGGL(mb_dstat_kernel, dim3((unsigned)m), dim3(kBlock), 0, st, dy, dstat, e, row, g, m);
     hipLaunchKernelGGL(mb_bwd_kernel, dim3((unsigned)bps, (unsigned)m), dim3(kBlock), 0, st, dy, x, dstat, dx, e, row, g, m);
     return mgx_launch_status();

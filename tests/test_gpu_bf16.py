@@ -500,8 +500,13 @@ def _fresh_gan(stage, micro_batch, budget_gib=None, seed=11):
 def test_bf16_upper_stage_micro_batches_equal_whole_batch(bf16_precision):
     """Stage 5 (128 x 24000), batch 8, bf16: the step in micro-batches of one MinibatchStdDev group against the
     whole batch at once.  Every sample's bf16 arithmetic is the same in both; only the float32 order in
-    which per-micro-batch gradient sums are added differs: metrics abs 1e-5, discriminator gradients rel-L2
-    5e-5 (5e-4 alpha), generator gradients 2e-2 (taken after the sign-like first Adam step of D)."""
+    which per-micro-batch gradient sums are added differs.  Both learning rates are set to 0 for this
+    comparison: a first Adam update is sign-like (beta_1 = 0, v = 0), so weights whose gradient is ~0 would
+    move by +-lr according to the last bit of a sum and everything evaluated after an update (the metric
+    blocks, the generator step) would compare two slightly different networks (measured: metrics 6e-5 after
+    the discriminator's update and 2e-2 after the generator's, generator gradients up to 9e-2) instead of
+    two summation orders.
+    Metrics abs 1e-5, discriminator gradients rel-L2 5e-5 (5e-4 alpha), generator gradients 2e-3."""
     from music_generator_amd.graph import FusedGroup
     stage, n = 5, 8
     gen = torch.Generator(device="cuda")
@@ -511,6 +516,7 @@ def test_bf16_upper_stage_micro_batches_equal_whole_batch(bf16_precision):
     try:
         for mb in (None, 4):
             gan = _fresh_gan(stage, mb)     # initial values are a function of the variable names: both builds equal
+            gan.d_optimizer.lr = gan.g_optimizer.lr = 0.0
             m = {k: float(v) for k, v in gan.train_step(real).items()}
             grads = {v.name: v.grad.cpu().numpy().copy() for model in (gan.discriminator, gan.generator)
                      for v in model.trainable_variables}
@@ -523,12 +529,17 @@ def test_bf16_upper_stage_micro_batches_equal_whole_batch(bf16_precision):
     (m0, g0), (m1, g1) = runs
     for k in m0:
         assert np.isfinite(m0[k]) and abs(m0[k] - m1[k]) < 1e-5, (k, m0[k], m1[k])
+    worst = {}
     for k, v in g0.items():
         assert np.isfinite(g1[k]).all(), k
         if np.abs(v).max() < 1e-12:
             continue
-        tol = (5e-4 if k.endswith("/alpha") else 5e-5) if k in d_names else 2e-2
-        assert rel_l2(g1[k], v) < tol, "%s: %.3e" % (k, rel_l2(g1[k], v))
+        which = "d" if k in d_names else "g"
+        err = rel_l2(g1[k], v)
+        worst[which] = max(worst.get(which, (0.0, "")), (err, k))
+        tol = (5e-4 if k.endswith("/alpha") else 5e-5) if which == "d" else 2e-3
+        assert err < tol, "%s: %.3e" % (k, err)
+    print("worst relative L2:", worst)
 
 
 def test_bf16_full_resolution_step_properties(bf16_precision):
