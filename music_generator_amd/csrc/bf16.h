@@ -72,3 +72,13 @@ __device__ __forceinline__ void act_bf16(float x, float inv_alpha, float k1, flo
     y = __builtin_fmaf(x, inv_alpha, t);
     dv = __builtin_fmaf(-t, t, k1);
 }
+
+// ds_read_b64_tr_b16: per group of 16 lanes a block of 4 rows x 16 columns of 16-bit elements; lane 4q+p
+// supplies the address of row q, columns 4p..4p+3 (8-byte aligned), lane i receives column i of the 4 rows.
+// All 64 lanes must be active.
+typedef short mgx_s16x4 __attribute__((ext_vector_type(4)));
+typedef __attribute__((address_space(3))) mgx_s16x4* mgx_lds_s16x4_ptr;
+__device__ __forceinline__ u32x2 tr_read(const unsigned char* p) {
+    return __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((mgx_lds_s16x4_ptr)p));
+}
+

@@ -21,13 +21,6 @@
 
 namespace {
 
-typedef short s16x4 __attribute__((ext_vector_type(4)));
-typedef __attribute__((address_space(3))) s16x4* lds_s16x4_ptr;
-
-__device__ __forceinline__ u32x2 tr_read(const unsigned char* p) {
-    return __builtin_bit_cast(u32x2, __builtin_amdgcn_ds_read_tr16_b64_v4i16((lds_s16x4_ptr)p));
-}
-
 constexpr int WTH = 8;
 
 template <int KH, int KW, bool S2>

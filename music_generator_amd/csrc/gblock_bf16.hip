@@ -50,8 +50,10 @@ constexpr int BO_E4 = BO_E3 + 8;
 constexpr int NBIAS = BO_E4 + 8;
 constexpr long PACKB_BYTES = (long)NFB * 1024 + NBIAS * 4;
 
+constexpr int TL_BYTES = 2048;                       // [32 positions][32 rows] bf16 transposition image; two per wave
 constexpr int BUF_BYTES = TAIL_HI * 1024;           // one phase buffer
-constexpr int LDS_BYTES = 4 * 1024 + 2 * BUF_BYTES; // featured fragments + two phase buffers
+constexpr int LDS_BYTES = 4 * 1024 + 2 * BUF_BYTES + 8 * TL_BYTES; // featured fragments + two phase buffers + the
+                                                                // waves' transposition images of the tape stores
 
 __global__ __launch_bounds__(256) void gblock_pack_bf16_kernel(mgx_gblock_weights w, unsigned char* __restrict__ packb) {
     const int idx = blockIdx.x * 256 + threadIdx.x;
@@ -140,15 +142,68 @@ __device__ __forceinline__ void store_pair(bf16_t* __restrict__ buf, int row, in
     p[(row + 1) * 32 + r] = (unsigned short)(u >> 16);
 }
 
-template <int NS>
-__device__ __forceinline__ void save_b(bf16_t* __restrict__ buf, int row0, const BTile& t, int r, int h) {
+// The 32 x 32 tile goes through a wave-private LDS image [position][row] (64 B a position, the eight 8-byte
+// chunks of a position XOR-swizzled with bits 1-3 of the position: conflict-free for the writes and for the
+// transposing reads) and comes back with ds_read_b64_tr_b16 as 8 consecutive positions of one row per lane:
+// one 16-byte store per lane and 16 rows, each store instruction 1 KiB of consecutive rows.  (Stored straight
+// from the B-tile registers a lane holds one position of a row: 2-byte stores, 16 instructions a tile, which
+// cost more than the tile's MFMAs.)
+__device__ __forceinline__ int tl_off(int pos, int chunk) { return pos * 64 + ((chunk ^ ((pos >> 1) & 7)) << 3); }
+
+// The image is double-buffered and the way out of a tile is deferred to the next call: a call first issues the
+// transposing reads of the PREVIOUS tile (written one call ago, nothing to wait for), then writes its own tile
+// into the other image, then stores what it read; tape_flush() stores the last tile of a sequence.
+struct TapeOut {
+    unsigned char* tl;          // the wave's two images
+    bf16_t* buf;                // pending tile: side buffer, first row, k-steps
+    int row0, ns, par;
+};
+
+__device__ __forceinline__ void tape_read(const TapeOut& o, int lane, u32x2 (&lo)[2], u32x2 (&hi)[2]) {
+    const int g16 = lane >> 4, i = lane & 15, q = i >> 2, p = i & 3;
+    const unsigned char* img = o.tl + (o.par ^ 1) * TL_BYTES;
 #pragma unroll
-    for (int s = 0; s < NS; ++s)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) {
-            const int row = row0 + chan(8 * s + 2 * q, h);
-            store_pair(buf, row, r, t.k[s][q]);
+    for (int u = 0; u < 2; ++u)                       // rows 16u .. 16u+15, positions 8 g16 .. 8 g16 + 7
+        if (u < o.ns) {
+            lo[u] = tr_read(img + tl_off(8 * g16 + q, 4 * u + p));
+            hi[u] = tr_read(img + tl_off(8 * g16 + 4 + q, 4 * u + p));
         }
+}
+
+__device__ __forceinline__ void tape_store(const TapeOut& o, int lane, const u32x2 (&lo)[2], const u32x2 (&hi)[2]) {
+    const int g16 = lane >> 4, i = lane & 15;
+#pragma unroll
+    for (int u = 0; u < 2; ++u)
+        if (u < o.ns)
+            *(u32x4*)((unsigned char*)o.buf + ((o.row0 + 16 * u + i) * 32 + 8 * g16) * 2) =
+                (u32x4){lo[u][0], lo[u][1], hi[u][0], hi[u][1]};
+}
+
+template <int NS>
+__device__ __forceinline__ void save_b(bf16_t* __restrict__ buf, int row0, const BTile& t, int r, int h, TapeOut& o) {
+    const int lane = r + 32 * h;
+    u32x2 lo[2], hi[2];
+    tape_read(o, lane, lo, hi);
+    // dwords 0-1 of k-step s are rows 16s + 4h + 0..3 (chunk 4s + h), dwords 2-3 rows 16s + 8 + 4h + 0..3
+    unsigned char* img = o.tl + o.par * TL_BYTES;
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+        *(u32x2*)(img + tl_off(r, 4 * s + h)) = (u32x2){t.k[s][0], t.k[s][1]};
+        *(u32x2*)(img + tl_off(r, 4 * s + 2 + h)) = (u32x2){t.k[s][2], t.k[s][3]};
+    }
+    tape_store(o, lane, lo, hi);
+    o.buf = buf;
+    o.row0 = row0;
+    o.ns = NS;
+    o.par ^= 1;
+}
+
+__device__ __forceinline__ void tape_flush(TapeOut& o, int r, int h) {
+    const int lane = r + 32 * h;
+    u32x2 lo[2], hi[2];
+    tape_read(o, lane, lo, hi);
+    tape_store(o, lane, lo, hi);
+    o.ns = 0;
 }
 
 __device__ __forceinline__ u32x4 frag(const unsigned char* buf, int f, int lane) {
@@ -175,6 +230,7 @@ __global__ __launch_bounds__(256, 1) void gblock_fwd_bf16_kernel(const unsigned 
     const float* bias = (const float*)(packb + (long)NFB * 1024);
     unsigned char* fbuf = lds;                               // featured fragments (4)
     unsigned char* pbuf = lds + 4 * 1024;                    // two phase buffers
+    TapeOut tl = {lds + 4 * 1024 + 2 * BUF_BYTES + wv * 2 * TL_BYTES, nullptr, 0, 0, 0};   // this wave's images
 
     // phase q of a sub-row: fragments [phase_f0(q), + phase_n(q))
     auto phase_f0 = [](int q) { return q < 6 ? FB_BR + q * BRF : (q == 6 ? FB_T : FB_T + TAIL_LO); };
@@ -218,7 +274,7 @@ __global__ __launch_bounds__(256, 1) void gblock_fwd_bf16_kernel(const unsigned 
                 init_bias(F, bias + BO_B0 + it * 32, h, 127, 4);
                 F = mfma_bf16(frag(fbuf, it, lane), xb, F);
                 Fb[it] = to_b(F);
-                if (SAVE && A == 0) save_b<2>(at, GB_F + it * 32, Fb[it], r, h);
+                if (SAVE && A == 0) save_b<2>(at, GB_F + it * 32, Fb[it], r, h, tl);
             }
             f32x16 S[2][4];
 #pragma unroll
@@ -238,12 +294,12 @@ __global__ __launch_bounds__(256, 1) void gblock_fwd_bf16_kernel(const unsigned 
                     for (int ks = 0; ks < 2; ++ks) o1 = mfma_bf16(frag(wb, FB_K1 + it * 2 + ks, lane), Fb[it].k[ks], o1);
                 const BTile o1b = to_b(o1);
                 bf16_t* abr = SAVE ? at + (GB_BR + k * GB_BR_ROWS) * 32 : nullptr;
-                if (SAVE && A == 0) save_b<2>(abr, GB_O1, o1b, r, h);
+                if (SAVE && A == 0) save_b<2>(abr, GB_O1, o1b, r, h, tl);
                 f32x16 o2;
                 init_bias(o2, bb + 16, h, 31, 4);
                 o2 = mfma_bf16(frag(wb, FB_D1, lane), A ? o1b.k[1] : o1b.k[0], o2);      // the 16 channels of sub-row A
                 const BTile o2b = to_b(o2);
-                if (SAVE) save_b<2>(abr, GB_O2 + A * 32, o2b, r, h);
+                if (SAVE) save_b<2>(abr, GB_O2 + A * 32, o2b, r, h, tl);
 #pragma unroll
                 for (int b = 0; b < 2; ++b) {
                     BTile o3b[2];
@@ -255,7 +311,7 @@ __global__ __launch_bounds__(256, 1) void gblock_fwd_bf16_kernel(const unsigned 
                         for (int ks = 0; ks < 2; ++ks)
                             o3 = mfma_bf16(frag(wb, FB_K2 + (b * 2 + ot) * 2 + ks, lane), o2b.k[ks], o3);
                         o3b[ot] = to_b(o3);
-                        if (SAVE) save_b<2>(abr, GB_O3 + (A * 2 + b) * 64 + ot * 32, o3b[ot], r, h);
+                        if (SAVE) save_b<2>(abr, GB_O3 + (A * 2 + b) * 64 + ot * 32, o3b[ot], r, h, tl);
                     }
 #pragma unroll
                     for (int ot = 0; ot < 4; ++ot)
@@ -275,7 +331,7 @@ __global__ __launch_bounds__(256, 1) void gblock_fwd_bf16_kernel(const unsigned 
 #pragma unroll
                 for (int it = 0; it < 4; ++it) {
                     Sb[b][it] = to_b(S[b][it]);
-                    if (SAVE) save_b<2>(at, GB_S + (A * 2 + b) * 128 + it * 32, Sb[b][it], r, h);
+                    if (SAVE) save_b<2>(at, GB_S + (A * 2 + b) * 128 + it * 32, Sb[b][it], r, h, tl);
                 }
             f32x16 T2[2][2];
 #pragma unroll
@@ -301,7 +357,7 @@ __global__ __launch_bounds__(256, 1) void gblock_fwd_bf16_kernel(const unsigned 
 #pragma unroll
                             for (int ks = 0; ks < 2; ++ks) T1 = mfma_bf16(frag(wc, it * 2 + ks, lane), Sb[b][it].k[ks], T1);
                         const BTile T1b = to_b(T1);
-                        if (SAVE) save_b<2>(at, GB_T1 + (A * 2 + b) * 256 + c * 32, T1b, r, h);
+                        if (SAVE) save_b<2>(at, GB_T1 + (A * 2 + b) * 256 + c * 32, T1b, r, h, tl);
 #pragma unroll
                         for (int ot = 0; ot < 2; ++ot)
 #pragma unroll
@@ -315,8 +371,8 @@ __global__ __launch_bounds__(256, 1) void gblock_fwd_bf16_kernel(const unsigned 
                     for (int b = 0; b < 2; ++b) {
                         const BTile t0 = to_b(T2[b][0]), t1 = to_b(T2[b][1]);
                         if (SAVE) {
-                            save_b<2>(at, GB_T2 + (A * 2 + b) * 64, t0, r, h);
-                            save_b<2>(at, GB_T2 + (A * 2 + b) * 64 + 32, t1, r, h);
+                            save_b<2>(at, GB_T2 + (A * 2 + b) * 64, t0, r, h, tl);
+                            save_b<2>(at, GB_T2 + (A * 2 + b) * 64 + 32, t1, r, h, tl);
                         }
                         f32x16 T3, O;
                         init_bias(T3, bias + BO_E3, h, 7, 1);
@@ -340,6 +396,7 @@ __global__ __launch_bounds__(256, 1) void gblock_fwd_bf16_kernel(const unsigned 
             }
         }
     }
+    if (SAVE) tape_flush(tl, r, h);
 }
 
 // ------------------------------------------------------------------------------------------
@@ -362,7 +419,7 @@ constexpr int PB_D1 = 24;                //   [ks 2], rows >= 16 zero
 constexpr int PB_K1 = 26;                //   [a 2][ot 4]
 constexpr int NFT = PT_BR + 6 * PBR;     // 312
 constexpr int TBUF_BYTES = PT_TAIL_LO * 1024;
-constexpr int TLDS_BYTES = 8 * 1024 + 2 * TBUF_BYTES;
+constexpr int TLDS_BYTES = 8 * 1024 + 2 * TBUF_BYTES + 8 * TL_BYTES;
 
 __global__ __launch_bounds__(256) void gblock_packT_bf16_kernel(mgx_gblock_weights w, unsigned char* __restrict__ packt) {
     const int idx = blockIdx.x * 256 + threadIdx.x;
@@ -424,6 +481,7 @@ __global__ __launch_bounds__(256, 1) void gblock_dgrad_bf16_kernel(const unsigne
     const int r = lane & 31, h = lane >> 5;
     unsigned char* kbuf = lds;                               // K0T fragments (8)
     unsigned char* pbuf = lds + 8 * 1024;                    // two phase buffers
+    TapeOut tl = {lds + 8 * 1024 + 2 * TBUF_BYTES + wv * 2 * TL_BYTES, nullptr, 0, 0, 0};  // this wave's images
     // phase q of a sub-row: 0 = tail-lo, 1 = tail-hi, 2..7 = branches
     auto phase_f0 = [](int q) { return q == 0 ? PT_TAIL : (q == 1 ? PT_TAIL + PT_TAIL_LO : PT_BR + (q - 2) * PBR); };
     auto phase_n = [](int q) { return q == 0 ? PT_TAIL_LO : (q == 1 ? PT_TAIL_HI : PBR); };
@@ -474,7 +532,7 @@ __global__ __launch_bounds__(256, 1) void gblock_dgrad_bf16_kernel(const unsigne
                             zero_tile(dT2);
                             dT2 = mfma_bf16(frag(wb, 1 + ot, lane), t3.k[0], dT2);
                             dT2b[b][ot] = to_b(dT2);
-                            save_b<2>(dt, GB_T2 + ab * 64 + ot * 32, dT2b[b][ot], r, h);
+                            save_b<2>(dt, GB_T2 + ab * 64 + ot * 32, dT2b[b][ot], r, h, tl);
                         }
                         if (h == 0) store_pair(dt, GB_X + ab * 2, r, ohi);
 #pragma unroll
@@ -497,7 +555,7 @@ __global__ __launch_bounds__(256, 1) void gblock_dgrad_bf16_kernel(const unsigne
 #pragma unroll
                             for (int ks = 0; ks < 2; ++ks) dT1 = mfma_bf16(frag(wc, it * 2 + ks, lane), dT2b[b][it].k[ks], dT1);
                         const BTile t1 = to_b(dT1);
-                        save_b<2>(dt, GB_T1 + (a * 2 + b) * 256 + c * 32, t1, r, h);
+                        save_b<2>(dt, GB_T1 + (a * 2 + b) * 256 + c * 32, t1, r, h, tl);
 #pragma unroll
                         for (int ot = 0; ot < 4; ++ot)
 #pragma unroll
@@ -514,7 +572,7 @@ __global__ __launch_bounds__(256, 1) void gblock_dgrad_bf16_kernel(const unsigne
 #pragma unroll
                 for (int ot = 0; ot < 4; ++ot) {
                     dSb[b][ot] = to_b(dS[b][ot]);
-                    save_b<2>(dt, GB_S + (a * 2 + b) * 128 + ot * 32, dSb[b][ot], r, h);
+                    save_b<2>(dt, GB_S + (a * 2 + b) * 128 + ot * 32, dSb[b][ot], r, h, tl);
                 }
             // ---- branches ----
 #pragma unroll 1
@@ -538,7 +596,7 @@ __global__ __launch_bounds__(256, 1) void gblock_dgrad_bf16_kernel(const unsigne
                             for (int ks = 0; ks < 2; ++ks)
                                 do3 = mfma_bf16(frag(wb, PB_D2 + (it * 4 + ot) * 2 + ks, lane), dSb[b][ot].k[ks], do3);
                         do3b[it] = to_b(do3);
-                        save_b<2>(dbr, GB_O3 + (a * 2 + b) * 64 + it * 32, do3b[it], r, h);
+                        save_b<2>(dbr, GB_O3 + (a * 2 + b) * 64 + it * 32, do3b[it], r, h, tl);
                     }
 #pragma unroll
                     for (int it = 0; it < 2; ++it)
@@ -547,13 +605,13 @@ __global__ __launch_bounds__(256, 1) void gblock_dgrad_bf16_kernel(const unsigne
                             do2 = mfma_bf16(frag(wb, PB_K2 + (b * 2 + it) * 2 + ks, lane), do3b[it].k[ks], do2);
                 }
                 const BTile do2b = to_b(do2);
-                save_b<2>(dbr, GB_O2 + a * 32, do2b, r, h);
+                save_b<2>(dbr, GB_O2 + a * 32, do2b, r, h, tl);
                 f32x16 do1;
                 zero_tile(do1);
                 do1 = mfma_bf16(frag(wb, PB_D1, lane), do2b.k[0], do1);
                 do1 = mfma_bf16(frag(wb, PB_D1 + 1, lane), do2b.k[1], do1);
                 const BTile do1b = to_b(do1);
-                save_b<1>(dbr, GB_O1 + a * 16, do1b, r, h);          // rows 0-15 = registers 0-7 of both lane halves
+                save_b<1>(dbr, GB_O1 + a * 16, do1b, r, h, tl);          // rows 0-15 = registers 0-7 of both lane halves
 #pragma unroll
                 for (int ot = 0; ot < 4; ++ot)
                     dF[ot] = mfma_bf16(frag(wb, PB_K1 + (a ? 4 : 0) + ot, lane), do1b.k[0], dF[ot]);
@@ -567,12 +625,13 @@ __global__ __launch_bounds__(256, 1) void gblock_dgrad_bf16_kernel(const unsigne
 #pragma unroll
         for (int it = 0; it < 4; ++it) {
             const BTile fb = to_b(dF[it]);
-            save_b<2>(dt, GB_F + it * 32, fb, r, h);
+            save_b<2>(dt, GB_F + it * 32, fb, r, h, tl);
             dxa = mfma_bf16(frag(kbuf, it * 2, lane), fb.k[0], dxa);
             dxa = mfma_bf16(frag(kbuf, it * 2 + 1, lane), fb.k[1], dxa);
         }
         if (pvalid && h == 0) *(float2*)(dx + pc * 2) = make_float2(dxa[0], dxa[1]);
     }
+    tape_flush(tl, r, h);
 }
 
 }  // namespace
