@@ -21,28 +21,31 @@
 // Epilogues: bias + tanh(x)+x/alpha (+ optional store of the derivative for the backward pass);
 // multiply by a bf16 tensor of the output's shape (the data-gradient of a convolution whose input came
 // out of an activation: dY (.) f'); or plain.
+#include <cstdlib>
 #include "bf16.h"
 #include "../../include/mgx.h"
 
 namespace {
 
-constexpr int TH = 8, TW = 64;
-
-template <int KH, int KW>
-constexpr int npix() { return (TH + KH - 1) * (TW + KW - 1); }
+// Tile shapes: TH rows (= waves of the workgroup) x NT * 32 columns.  8 x 64 (8 waves, two accumulator tiles
+// a wave) and 16 x 32 (16 waves = 4 per SIMD, one accumulator tile a wave: twice the waves to cover the
+// latencies of a step, 1.20 instead of 1.29 input rows and columns read per output with a 3x3 halo).
+template <int KH, int KW, int TH, int NT>
+constexpr int npix() { return (TH + KH - 1) * (NT * 32 + KW - 1); }
 
 // byte offset of quad q (8 channels) of tile position p
 __device__ __forceinline__ int xoff(int p, int q) { return p * 64 + ((q ^ ((p >> 2) & 3)) << 4); }
 
-template <int KH, int KW, int EPI>
-__global__ __launch_bounds__(512, 2) void bconv_kernel(mgx_conv_desc d, const bf16_t* __restrict__ x,
+template <int KH, int KW, int EPI, int TH, int NT>
+__global__ __launch_bounds__(64 * TH) void bconv_kernel(mgx_conv_desc d, const bf16_t* __restrict__ x,
                                                        const float* __restrict__ w, const float* __restrict__ bias,
                                                        bf16_t* __restrict__ y, bf16_t* __restrict__ dact,
                                                        const bf16_t* __restrict__ ymul, long ntiles, int tiles_h,
                                                        int tiles_w, int gin_w, int scat) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    constexpr int TW = NT * 32, NTHR = 64 * TH;
     constexpr int IH = TH + KH - 1, IW = TW + KW - 1, TAPS = KH * KW, NPIX = IH * IW;
-    constexpr int SITER = (NPIX * 4 + 511) / 512;            // 16-byte staging loads per thread
+    constexpr int SITER = (NPIX * 4 + NTHR - 1) / NTHR;      // 16-byte staging loads per thread
     const int tid = threadIdx.x;
     const int lane = tid & 63;
     const int r = lane & 31, h = lane >> 5;
@@ -58,7 +61,7 @@ __global__ __launch_bounds__(512, 2) void bconv_kernel(mgx_conv_desc d, const bf
     {
         const int total = TAPS * K * N;
         const bool n_fast = d.wsn == 1;
-        for (int i = tid; i < total; i += 512) {
+        for (int i = tid; i < total; i += NTHR) {
             int tap, k, n;
             if (n_fast) { n = i % N; const int t2 = i / N; k = t2 % K; tap = t2 / K; }
             else { k = i % K; const int t2 = i / K; n = t2 % N; tap = t2 / N; }
@@ -86,7 +89,7 @@ __global__ __launch_bounds__(512, 2) void bconv_kernel(mgx_conv_desc d, const bf
     int rel[SITER], tyx[SITER];
 #pragma unroll
     for (int i = 0; i < SITER; ++i) {
-        const int px = (tid >> 2) + 128 * i;
+        const int px = (tid >> 2) + (NTHR / 4) * i;
         const int ty = px / IW, tx = px - ty * IW;
         rel[i] = gin_w > 0 ? ((ty * 2 * gin_w + 2 * tx) * 32 + q4 * 8) * 2 : ((ty * W + tx) * d.cin + q4 * 8) * 2;
         tyx[i] = px < NPIX ? ((ty << 16) | tx) : (0x7000 << 16);
@@ -109,8 +112,8 @@ __global__ __launch_bounds__(512, 2) void bconv_kernel(mgx_conv_desc d, const bf
     auto stage_write = [&](unsigned char* buf) {
 #pragma unroll
         for (int i = 0; i < SITER; ++i) {
-            const int px = (tid >> 2) + 128 * i;
-            if (128 * (i + 1) <= NPIX || px < NPIX) *(u32x4*)(buf + xoff(px, q4)) = sv[i];
+            const int px = (tid >> 2) + (NTHR / 4) * i;
+            if ((NTHR / 4) * (i + 1) <= NPIX || px < NPIX) *(u32x4*)(buf + xoff(px, q4)) = sv[i];
         }
     };
 
@@ -124,31 +127,60 @@ __global__ __launch_bounds__(512, 2) void bconv_kernel(mgx_conv_desc d, const bf
     const float inv_alpha = d.act_alpha > 0.f ? 1.0f / d.act_alpha : 0.f;
     const float k1 = 1.0f + inv_alpha;
     int cur = 0;
-    f32x16 acc0, acc1;
+    f32x16 acc[NT];
 #pragma unroll
-    for (int i = 0; i < 16; ++i) { acc0[i] = 0.f; acc1[i] = 0.f; }
+    for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[nt][i] = 0.f;
 
     // ---- epilogue of the wave's row of tile t_, output channel chunk nc_ ----
-    auto epilogue = [&](f32x16& a0, f32x16& a1, long t_, int nc_) {
-        long img; int h0, w0;
+    // values the epilogue of this step needs from global memory, requested before the MFMA phase so that
+    // their latency is covered by it: the 16 biases of the lane's channels, or the lane's 2 x 32 bytes of `ymul`
+    f32x4 pre_b[4];
+    u32x4 pre_m[NT][2];
+    auto epilogue_addr = [&](long t_, int nc_, long& rowoff, unsigned& row_bytes, int& pstride, int& coff, int& w0) {
+        long img; int h0;
         tile_of(t_, img, h0, w0);
         const int row = h0 + wvs;
-        const long rowoff = scat ? ((img * 2 * H + 2 * row + (nc_ >> 1)) * (2L * W)) * 32
-                                 : ((img * H + row) * (long)W) * N;
-        const unsigned row_bytes = row < H ? (scat ? 2u * W * 64u : (unsigned)W * N * 2u) : 0u;
+        rowoff = scat ? ((img * 2 * H + 2 * row + (nc_ >> 1)) * (2L * W)) * 32 : ((img * H + row) * (long)W) * N;
+        row_bytes = row < H ? (scat ? 2u * W * 64u : (unsigned)W * N * 2u) : 0u;
+        pstride = scat ? 128 : N * 2;                   // bytes between consecutive columns
+        coff = scat ? (nc_ & 1) * 64 + 16 * h : nc_ * 64 + 16 * h;    // the lane's first 16 bytes; the second 32 further
+    };
+    auto epilogue_prefetch = [&](long t_, int nc_) {
+        if (EPI == 1) {
+#pragma unroll
+            for (int g = 0; g < 4; ++g)         // channels 8h .. 8h+7 and 16+8h .. 16+8h+7 (acc_rows_interleaved)
+                pre_b[g] = d.nbias > 0 ? *(const f32x4*)(bias + nc_ * 32 + 8 * h + 16 * (g >> 1) + 4 * (g & 1))
+                                       : (f32x4){0.f, 0.f, 0.f, 0.f};
+        }
+        if (EPI == 2) {
+            long rowoff; unsigned row_bytes; int pstride, coff, w0;
+            epilogue_addr(t_, nc_, rowoff, row_bytes, pstride, coff, w0);
+            const __amdgpu_buffer_rsrc_t rm =
+                __builtin_amdgcn_make_buffer_rsrc((void*)(ymul + rowoff), 0, row_bytes, 0x00020000);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                const unsigned voff = (unsigned)((w0 + nt * 32 + r) * pstride + coff);
+                pre_m[nt][0] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rm, voff, 0, 0));
+                pre_m[nt][1] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rm, voff + 32, 0, 0));
+            }
+        }
+    };
+    auto epilogue = [&](f32x16 (&av)[NT], long t_, int nc_) {
+        long rowoff; unsigned row_bytes; int pstride, coff, w0;
+        epilogue_addr(t_, nc_, rowoff, row_bytes, pstride, coff, w0);
         const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc((void*)(y + rowoff), 0, row_bytes, 0x00020000);
-        const int pstride = scat ? 128 : N * 2;                   // bytes between consecutive columns
-        const int coff = scat ? (nc_ & 1) * 64 + 32 * h : (nc_ * 32 + 16 * h) * 2;
         float bv[16];
         if (EPI == 1) {
 #pragma unroll
-            for (int i = 0; i < 16; ++i) bv[i] = d.nbias > 0 ? bias[nc_ * 32 + 16 * h + i] : 0.f;
+            for (int i = 0; i < 16; ++i) bv[i] = pre_b[i >> 2][i & 3];
         }
         mfma_result_wait();
 #pragma unroll
-        for (int nt = 0; nt < 2; ++nt) {
-            f32x16& a = nt ? a1 : a0;
-            acc_rows_contiguous(a);
+        for (int nt = 0; nt < NT; ++nt) {
+            f32x16& a = av[nt];
+            acc_rows_interleaved(a);
             const unsigned voff = (unsigned)((w0 + nt * 32 + r) * pstride + coff);
             unsigned o[8], dd[8];
             if (EPI == 1) {
@@ -166,10 +198,7 @@ __global__ __launch_bounds__(512, 2) void bconv_kernel(mgx_conv_desc d, const bf
                     for (int i = 0; i < 16; i += 2) o[i >> 1] = bf_pack(a[i] + bv[i], a[i + 1] + bv[i + 1]);
                 }
             } else if (EPI == 2) {
-                const __amdgpu_buffer_rsrc_t rm =
-                    __builtin_amdgcn_make_buffer_rsrc((void*)(ymul + rowoff), 0, row_bytes, 0x00020000);
-                const u32x4 m0 = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rm, voff, 0, 0));
-                const u32x4 m1 = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rm, voff + 16, 0, 0));
+                const u32x4 m0 = pre_m[nt][0], m1 = pre_m[nt][1];
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
                     o[i] = bf_pack(a[2 * i] * bf_lo(m0[i]), a[2 * i + 1] * bf_hi(m0[i]));
@@ -181,13 +210,13 @@ __global__ __launch_bounds__(512, 2) void bconv_kernel(mgx_conv_desc d, const bf
             }
             u32x4 s0 = {o[0], o[1], o[2], o[3]}, s1 = {o[4], o[5], o[6], o[7]};
             __builtin_amdgcn_raw_buffer_store_b128(s0, ry, voff, 0, 0);
-            __builtin_amdgcn_raw_buffer_store_b128(s1, ry, voff + 16, 0, 0);
+            __builtin_amdgcn_raw_buffer_store_b128(s1, ry, voff + 32, 0, 0);
             if (EPI == 1 && dact != nullptr && d.act_alpha > 0.f) {
                 const __amdgpu_buffer_rsrc_t rd =
                     __builtin_amdgcn_make_buffer_rsrc((void*)(dact + rowoff), 0, row_bytes, 0x00020000);
                 u32x4 e0 = {dd[0], dd[1], dd[2], dd[3]}, e1 = {dd[4], dd[5], dd[6], dd[7]};
                 __builtin_amdgcn_raw_buffer_store_b128(e0, rd, voff, 0, 0);
-                __builtin_amdgcn_raw_buffer_store_b128(e1, rd, voff + 16, 0, 0);
+                __builtin_amdgcn_raw_buffer_store_b128(e1, rd, voff + 32, 0, 0);
             }
         }
     };
@@ -199,6 +228,8 @@ __global__ __launch_bounds__(512, 2) void bconv_kernel(mgx_conv_desc d, const bf
         const bool has_next = tn < ntiles;
         const bool need_x = has_next && (kchunks > 1 || ocn == 0);
         if (need_x) stage_load(tn, kchunks > 1 ? ocn : 0);
+        const bool ep_now = kchunks == 1 || oc == S - 1;
+        if (ep_now) epilogue_prefetch(t, nchunks > 1 ? oc : 0);
         const unsigned char* xb = xt + cur * (NPIX * 64);
         const int kc = kchunks > 1 ? oc : 0, nc = nchunks > 1 ? oc : 0;
         const unsigned char* wb = wl + ((nc * TAPS * (K >> 4) + kc * 2) * 64 + lane) * 16;
@@ -209,17 +240,18 @@ __global__ __launch_bounds__(512, 2) void bconv_kernel(mgx_conv_desc d, const bf
 #pragma unroll
             for (int ks = 0; ks < 2; ++ks) {
                 const u32x4 a = *(const u32x4*)(wb + (tap * (K >> 4) + ks) * 1024);
-                const u32x4 b0 = *(const u32x4*)(xb + xoff(p0, 2 * ks + h));
-                const u32x4 b1 = *(const u32x4*)(xb + xoff(p0 + 32, 2 * ks + h));
-                acc0 = mfma_bf16(a, b0, acc0);
-                acc1 = mfma_bf16(a, b1, acc1);
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt)
+                    acc[nt] = mfma_bf16(a, *(const u32x4*)(xb + xoff(p0 + 32 * nt, 2 * ks + h)), acc[nt]);
             }
         }
         if (need_x) stage_write(xt + (cur ^ 1) * (NPIX * 64));
-        if (kchunks == 1 || oc == S - 1) {
-            epilogue(acc0, acc1, t, nc);
+        if (ep_now) {
+            epilogue(acc, t, nc);
 #pragma unroll
-            for (int i = 0; i < 16; ++i) { acc0[i] = 0.f; acc1[i] = 0.f; }
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int i = 0; i < 16; ++i) acc[nt][i] = 0.f;
         }
         __syncthreads();
         if (need_x) cur ^= 1;
@@ -228,29 +260,42 @@ __global__ __launch_bounds__(512, 2) void bconv_kernel(mgx_conv_desc d, const bf
     }
 }
 
-template <int KH, int KW>
-int launch_b(const mgx_conv_desc& d, const bf16_t* x, const float* w, const float* bias, bf16_t* y, bf16_t* dact,
-             const bf16_t* ymul, hipStream_t st, int gin_w, int scat) {
+template <int KH, int KW, int TH, int NT>
+int launch_shape(const mgx_conv_desc& d, const bf16_t* x, const float* w, const float* bias, bf16_t* y, bf16_t* dact,
+                 const bf16_t* ymul, hipStream_t st, int gin_w, int scat) {
+    constexpr int TW = NT * 32;
     const int tiles_h = (d.hin + TH - 1) / TH, tiles_w = (d.win + TW - 1) / TW;
     const long ntiles = (long)d.nimg * tiles_h * tiles_w;
     if (ntiles <= 0 || ntiles >= (1L << 31)) return MGX_ERR_ARG;
     const unsigned grid = (unsigned)(ntiles < 256 ? ntiles : 256);
-    const int lds = KH * KW * d.cin * d.ngemm * 2 + 2 * npix<KH, KW>() * 64;
+    const int lds = KH * KW * d.cin * d.ngemm * 2 + 2 * npix<KH, KW, TH, NT>() * 64;
     if (lds > 160 * 1024) return MGX_ERR_ARG;
     const int epi = ymul != nullptr ? 2 : ((d.nbias > 0 || d.act_alpha > 0.f) ? 1 : 0);
 #define MGX_B(E)                                                                                                     \
     do {                                                                                                             \
-        if (hipFuncSetAttribute((const void*)bconv_kernel<KH, KW, E>, hipFuncAttributeMaxDynamicSharedMemorySize,    \
-                                lds) != hipSuccess)                                                                  \
+        if (hipFuncSetAttribute((const void*)bconv_kernel<KH, KW, E, TH, NT>,                                        \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)                      \
             return MGX_ERR_LAUNCH;                                                                                   \
-        hipLaunchKernelGGL((bconv_kernel<KH, KW, E>), dim3(grid), dim3(512), lds, st, d, x, w, bias, y, dact, ymul,  \
-                           ntiles, tiles_h, tiles_w, gin_w, scat);                                                   \
+        hipLaunchKernelGGL((bconv_kernel<KH, KW, E, TH, NT>), dim3(grid), dim3(64 * TH), lds, st, d, x, w, bias, y,  \
+                           dact, ymul, ntiles, tiles_h, tiles_w, gin_w, scat);                                       \
     } while (0)
     if (epi == 2) MGX_B(2);
     else if (epi == 1) MGX_B(1);
     else MGX_B(0);
 #undef MGX_B
     return mgx_launch_status();
+}
+
+// 16 x 32 tiles (16 waves) where the image has the rows to fill them and both tile buffers fit beside the
+// weights; 8 x 64 tiles otherwise.  MGX_BCONV_TILE=8 / 16 forces a shape (measurements).
+template <int KH, int KW>
+int launch_b(const mgx_conv_desc& d, const bf16_t* x, const float* w, const float* bias, bf16_t* y, bf16_t* dact,
+             const bf16_t* ymul, hipStream_t st, int gin_w, int scat) {
+    const int lds16 = KH * KW * d.cin * d.ngemm * 2 + 2 * npix<KH, KW, 16, 1>() * 64;
+    bool tall = d.hin >= 16 && d.hin % 16 == 0 && lds16 <= 160 * 1024;
+    if (const char* e = getenv("MGX_BCONV_TILE")) tall = e[0] == '1' && lds16 <= 160 * 1024;
+    if (tall) return launch_shape<KH, KW, 16, 1>(d, x, w, bias, y, dact, ymul, st, gin_w, scat);
+    return launch_shape<KH, KW, 8, 2>(d, x, w, bias, y, dact, ymul, st, gin_w, scat);
 }
 
 }  // namespace

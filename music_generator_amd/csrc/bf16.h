@@ -35,6 +35,25 @@ __device__ __forceinline__ f32x16 mfma_bf16(u32x4 a, u32x4 b, f32x16 c) {
 // (the compiler pads vector-ALU readers it schedules itself, but nothing inside or in front of asm).
 __device__ __forceinline__ void mfma_result_wait() { asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 3"); }
 
+// After this exchange between lanes l and l^32, lane (r, h) holds rows 8h .. 8h+7 of column r of a 32x32
+// accumulator tile in a[0..7] and rows 16+8h .. 16+8h+7 in a[8..15]: as bf16 the two lanes of a column hold
+// bytes [16h, 16h+16) and [32+16h, 32+16h+16) of its 64, so one 16-byte store instruction of the wave
+// writes 32 consecutive bytes of every column (whole 32-byte sectors).
+__device__ __forceinline__ void acc_rows_interleaved(f32x16& a) {
+#pragma unroll
+    for (int g = 0; g < 2; ++g) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+            // first operand: registers 8g+e (lanes >= 32: rows 16g+4+e), second: registers 8g+4+e (lanes < 32:
+            // rows 16g+8+e); the swap exchanges the first's upper lanes with the second's lower lanes
+            float lo = a[8 * g + e], hi = a[8 * g + 4 + e];
+            asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(lo), "+v"(hi));
+            a[8 * g + e] = lo;
+            a[8 * g + 4 + e] = hi;
+        }
+    }
+}
+
 // After this exchange between lanes l and l^32, lane (r, h) holds rows 16h .. 16h+15 of column r
 // of a 32x32 accumulator tile in a[0..15] (in order).
 __device__ __forceinline__ void acc_rows_contiguous(f32x16& a) {
