@@ -355,8 +355,12 @@ def main():
             raise SystemExit("--graph is a single-GPU mode")
         gan.use_graph = True
         args.warmup = max(args.warmup, 2)        # eager step, then the capturing step
+    trace = (lambda msg: print("[bench rank %d] %s" % (rank, msg), file=sys.stderr, flush=True)) \
+        if os.environ.get("MGX_BENCH_TRACE") else (lambda msg: None)
+    trace("models built")
     if dist is not None:
         dist.broadcast_weights(gan.discriminator, gan.generator)
+    trace("weights broadcast")
     gan.seed(1234 + rank)
     h, w = 4 << stage, 750 << stage
     gen = torch.Generator(device="cuda")
@@ -372,7 +376,9 @@ def main():
 
     for _ in range(args.warmup):
         gan.train_step(real)
+        trace("warm-up step enqueued")
     sync()
+    trace("warm-up done")
     prof = None if args.graph else ops.LaunchProfiler()
     ops.PROFILER = prof
     t0 = time.perf_counter()

@@ -545,8 +545,11 @@ class WGAN:
         # Off by default so that a step runs every pass the reference runs.
         self.reuse_real_logits = False
         # True: train_step captures the whole step into one HIP graph (per batch shape) the second
-        # time it sees a shape and replays it from then on; see _graphed_step.
-        self.use_graph = False
+        # time it sees a shape and replays it from then on; see _graphed_step.  None (default): decided
+        # per call, on for the small batches whose step is bound by the launch rate (up to GRAPH_AUTO_BATCH
+        # samples; the reference's own batch sizes are 16 and fewer) whenever nothing in the way of a
+        # capture is attached (see _graph_wanted).  False: never.
+        self.use_graph = None
         # True: the discriminator step keeps its logits (last_logits = {"fake", "real"}: (n,) device tensors in
         # batch order) for comparison against a reference; off by default (one gather per step)
         self.keep_logits = False
@@ -658,7 +661,7 @@ class WGAN:
             real_images = real_images[0]
         alpha = self._fade_alpha()              # validates set_train_steps before anything touches the device
         real = self.discriminator._to_device(real_images)
-        if self.use_graph:
+        if self._graph_wanted(real):
             return self._graphed_step(real)
         if alpha is not None:
             for layer in self._fade_layers():
@@ -666,6 +669,15 @@ class WGAN:
         out = self._step_body(real)
         self.actual_step += 1
         return out
+
+    GRAPH_AUTO_BATCH = 16
+
+    def _graph_wanted(self, real) -> bool:
+        if self.use_graph is not None:
+            return bool(self.use_graph)
+        return (real.shape[0] <= self.GRAPH_AUTO_BATCH and self.dist is None and self.d_steps == 1
+                and not self._latents and ops.PROFILER is None and not self.keep_logits
+                and not self.micro_batch and not torch.cuda.is_current_stream_capturing())
 
     def _fade_alpha(self):
         """models.py:78-82: alpha = actual_step / (train_steps - 1) on fade-in models."""

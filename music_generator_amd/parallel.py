@@ -94,7 +94,14 @@ class DataParallel:
                 for v in layer.weights:
                     if id(v) not in seen:
                         seen.add(id(v))
-                        dist.broadcast(v.value(), src=0)
+                        t = v.value()
+                        if t.is_cuda and dist.get_backend() != "nccl":
+                            # gloo rehearsal with device tensors: broadcast a host copy (as all_reduce does)
+                            host = t.detach().cpu()
+                            dist.broadcast(host, src=0)
+                            t.copy_(host)
+                        else:
+                            dist.broadcast(t, src=0)
 
     def barrier(self):
         if self.world_size > 1:

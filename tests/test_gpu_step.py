@@ -601,7 +601,7 @@ def test_bench_starts_its_own_ranks():
     env = dict(os.environ, MGX_BENCH_BACKEND="gloo")
     env.pop("WORLD_SIZE", None)
     res = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--stage", "1", "--batch", "8",
-                          "--steps", "2", "--warmup", "1"], env=env, capture_output=True, text=True, timeout=280)
+                          "--steps", "2", "--warmup", "1"], env=env, capture_output=True, text=True, timeout=150)
     assert res.returncode == 0, res.stderr[-2000:]
     lines = [l for l in res.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, res.stdout[-2000:]
