@@ -134,13 +134,24 @@ __global__ __launch_bounds__(kBlock) void pw2_wgrad_kernel(const float* __restri
     }
 }
 
-__global__ __launch_bounds__(128) void pw2_wgrad_reduce_kernel(const float* __restrict__ partial, float* __restrict__ dw,
-                                                               float* __restrict__ db, int nblocks) {
-    const int e = blockIdx.x * 128 + threadIdx.x;        // 0..383
+// 1024 threads = 16 consecutive sums x 64 groups of partial blocks (group g adds blocks g, g+64, ... in order),
+// then the 64 group sums in a fixed order: reproducible, and ~16 dependent loads a thread instead of ~10^3.
+__global__ __launch_bounds__(1024) void pw2_wgrad_reduce_kernel(const float* __restrict__ partial, float* __restrict__ dw,
+                                                                float* __restrict__ db, int nblocks) {
+    __shared__ double red[64][16];
+    const int el = threadIdx.x & 15, g = threadIdx.x >> 4;
+    const int e = blockIdx.x * 16 + el;                  // 0..383
     double s = 0.0;
-    for (int b = 0; b < nblocks; ++b) s += (double)partial[(long)b * 384 + e];
-    if (e < 256) dw[e] += (float)s;
-    else if (db) db[e - 256] += (float)s;
+    for (int b = g; b < nblocks; b += 64) s += (double)partial[(long)b * 384 + e];
+    red[g][el] = s;
+    __syncthreads();
+    if (g == 0) {
+        double t = 0.0;
+#pragma unroll
+        for (int q = 0; q < 64; ++q) t += red[q][el];
+        if (e < 256) dw[e] += (float)t;
+        else if (db) db[e - 256] += (float)t;
+    }
 }
 
 // dx[p][c] (+)= sum_k g[p][k] W[c][k]  (128 bf16 channels -> 2 float32 channels)
@@ -305,7 +316,7 @@ extern "C" int mgx_pointwise2_bf16_wgrad(const float* x, const void* g, float* d
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(pw2_wgrad_kernel, dim3(blocks), dim3(kBlock), 0, st, x, (const bf16_t*)g, (float*)workspace,
                        (long)npos);
-    hipLaunchKernelGGL(pw2_wgrad_reduce_kernel, dim3(3), dim3(128), 0, st, (const float*)workspace, dw, db, (int)blocks);
+    hipLaunchKernelGGL(pw2_wgrad_reduce_kernel, dim3(24), dim3(1024), 0, st, (const float*)workspace, dw, db, (int)blocks);
     return mgx_launch_status();
 }
 

@@ -430,20 +430,29 @@ __global__ __launch_bounds__(kBlock) void mb_bwd4_kernel(const float4* __restric
 }
 
 // ---------------- Flatten + Dense(1) ----------------
-__global__ __launch_bounds__(kBlock) void dense1_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
-                                                            const float* __restrict__ b, float* __restrict__ y, long e) {
-    __shared__ double red[4];
+// One block of 1024 threads per sample (the batch is small where this layer's latency matters: a sample is
+// ~10^5 elements, so 256 threads would walk it in ~120 dependent steps); the 16 wave sums are added in order.
+__global__ __launch_bounds__(1024) void dense1_fwd_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                          const float* __restrict__ b, float* __restrict__ y, long e) {
+    __shared__ double red[16];
     const long i = blockIdx.x;
     const float* src = x + i * e;
     double s = 0.0;
-    const long e4 = e / 4;
-    for (long j = threadIdx.x; j < e4; j += kBlock) {
+    const long e4 = (e & 3) == 0 ? e / 4 : 0;        // 16-byte loads need every sample's base aligned
+    for (long j = threadIdx.x; j < e4; j += 1024) {
         const float4 a = ((const float4*)src)[j], c = ((const float4*)w)[j];
-        s += (double)a.x * c.x + (double)a.y * c.y + (double)a.z * c.z + (double)a.w * c.w;
+        s += (double)(a.x * c.x + a.y * c.y) + (double)(a.z * c.z + a.w * c.w);
     }
-    for (long j = e4 * 4 + threadIdx.x; j < e; j += kBlock) s += (double)src[j] * w[j];
-    const double t = block_sum256_d(s, red);
-    if (threadIdx.x == 0) y[i] = (float)(t + (double)(b ? b[0] : 0.f));
+    for (long j = e4 * 4 + threadIdx.x; j < e; j += 1024) s += (double)src[j] * w[j];
+    s = wave_sum_d(s);
+    if ((threadIdx.x & 63) == 0) red[threadIdx.x >> 6] = s;
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double t = 0.0;
+#pragma unroll
+        for (int q = 0; q < 16; ++q) t += red[q];
+        y[i] = (float)(t + (double)(b ? b[0] : 0.f));
+    }
 }
 
 __global__ __launch_bounds__(kBlock) void dense1_bwd_kernel(const float* __restrict__ dy, const float* __restrict__ x,
@@ -693,7 +702,7 @@ extern "C" int mgx_mbstd_bwd(const float* dy, const float* x, float* dx, int64_t
 extern "C" int mgx_dense1_fwd(const float* x, const float* w, const float* b, float* y, int64_t n, int64_t e,
                               void* stream) {
     if (!x || !w || !y || n <= 0 || e <= 0 || n > 0x7fffffffL) return MGX_ERR_ARG;
-    hipLaunchKernelGGL(dense1_fwd_kernel, dim3((unsigned)n), dim3(kBlock), 0, (hipStream_t)stream, x, w, b, y, (long)e);
+    hipLaunchKernelGGL(dense1_fwd_kernel, dim3((unsigned)n), dim3(1024), 0, (hipStream_t)stream, x, w, b, y, (long)e);
     return mgx_launch_status();
 }
 
