@@ -38,7 +38,7 @@ def shard_indices(n_global: int, rank: int, world_size: int) -> np.ndarray:
 class DataParallel:
     """Process-group handle attached to a WGAN (`wgan.dist = DataParallel()`)."""
 
-    def __init__(self, backend: Optional[str] = None, init: bool = True):
+    def __init__(self, backend: Optional[str] = None, init: bool = True, force_collectives: bool = False):
         if init and not dist.is_initialized():
             backend = backend or ("nccl" if torch.cuda.is_available() else "gloo")
             os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -48,10 +48,13 @@ class DataParallel:
             dist.init_process_group(backend=backend)
         self.world_size = dist.get_world_size() if dist.is_initialized() else 1
         self.rank = dist.get_rank() if dist.is_initialized() else 0
+        # collectives are skipped in a group of one unless forced (a one-rank group still runs every call
+        # through the backend: the way to execute the RCCL path on a box with a single GPU)
+        self.active = dist.is_initialized() and (self.world_size > 1 or force_collectives)
 
     def all_reduce(self, t: torch.Tensor):
         """In-place sum over ranks, enqueued on the current stream (RCCL) / blocking (gloo)."""
-        if self.world_size > 1:
+        if self.active:
             if t.is_cuda and dist.get_backend() != "nccl":
                 # gloo rehearsal with device tensors: reduce a host copy
                 host = t.detach().cpu()
@@ -65,7 +68,7 @@ class DataParallel:
         """Start an in-place sum over ranks that runs beside the kernels enqueued after this call
         (RCCL uses its own stream, ordered after the work already on the current one).  Returns a
         handle for wait_for(); None when there is nothing to do."""
-        if self.world_size > 1:
+        if self.active:
             if dist.get_backend() != "nccl":      # gloo rehearsal: reduce in place now
                 self.all_reduce(t)
                 return None
@@ -86,7 +89,7 @@ class DataParallel:
 
     def broadcast_weights(self, *models):
         """Make every replica start from rank 0's weights."""
-        if self.world_size == 1:
+        if not self.active:
             return
         seen = set()
         for model in models:
@@ -104,5 +107,5 @@ class DataParallel:
                             dist.broadcast(t, src=0)
 
     def barrier(self):
-        if self.world_size > 1:
+        if self.active:
             dist.barrier()

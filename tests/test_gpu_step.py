@@ -418,6 +418,38 @@ def test_two_rank_device_step_equals_single_process(tmp_path):
                 assert rel_l2(b[k], a[k]) < tol, "%s: %.3e" % (k, rel_l2(b[k], a[k]))
 
 
+def test_rccl_path_executes_in_a_group_of_one(tmp_path):
+    """The `nccl` backend (= RCCL) needs one device per rank, so a one-GPU box cannot run two ranks; a process
+    group of ONE rank with the collectives forced (DataParallel(force_collectives=True)) still sends every
+    call of the data-parallel step through RCCL: the weight broadcast, the three asynchronous gradient
+    all-reduces on RCCL's stream with their waits, the blocking 2-float logit-sum all-reduces.  Sums over one
+    rank change nothing: the step (in micro-batches of 4) must equal the plain single-process step (metrics
+    abs 1e-5; gradients as for micro-batching)."""
+    import subprocess
+    import sys
+    root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+    script = os.path.join(root, "tests", "dp_worker.py")
+    single, rccl = str(tmp_path / "single.npz"), str(tmp_path / "rccl.npz")
+    env = dict(os.environ, OMP_NUM_THREADS="2")
+    for k in ("RANK", "WORLD_SIZE", "LOCAL_RANK"):
+        env.pop(k, None)
+    out = subprocess.run([sys.executable, str(script), root, single], env=env, capture_output=True, text=True,
+                         timeout=100)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    out = subprocess.run([sys.executable, str(script), root, rccl], env=dict(env, MGX_DP_RCCL_ONE="1", MGX_DP_TRACE="1"),
+                         capture_output=True, text=True, timeout=150)
+    assert out.returncode == 0, out.stdout[-2000:] + out.stderr[-2000:]
+    assert out.stdout.count("all_reduce_async begin") == 3 and out.stdout.count("wait_for end") == 3, out.stdout[-3000:]
+    with np.load(single) as a, np.load(rccl) as b:
+        for k in a.files:
+            if k.startswith("m|"):
+                assert abs(float(a[k]) - float(b[k])) < 1e-5, k
+            elif np.abs(a[k]).max() >= 1e-12:
+                name = k[2:]
+                tol = 5e-5 if not name.startswith(("dense_", "conv2d_transpose", "layer_norm", "weighted_sum_1")) else 2e-3
+                assert rel_l2(b[k], a[k]) < tol, "%s: %.3e" % (k, rel_l2(b[k], a[k]))
+
+
 def test_progressive_schedule_two_stages():
     """trainer/task.py:108-184 on the device with a tiny in-memory dataset: stage 0 fit, then the
     stage-1 fade-in twin (alpha ramps 0 -> 1 over its steps) and the straight-through twin, which
