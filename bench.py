@@ -124,6 +124,13 @@ def _norm(name):
     return name.replace(", ", ",")
 
 
+def _is_instance(table_key, kernel):
+    """`kernel` is a profiler key (`wino3_kernel`, `bconv_kernel<3,3,1>`); the tables hold full template
+    instances (`wino3_kernel<1,2,false,32>`, `bconv_kernel<3,3,1,16,1>`)."""
+    tk = _norm(table_key)
+    return tk == kernel or tk.startswith(kernel + "<") or (kernel.endswith(">") and tk.startswith(kernel[:-1] + ","))
+
+
 def measured_traffic(kernel, workload):
     """HBM bytes per launch of `kernel` from the committed PMC passes (profiles/pmc_traffic.json:
     2 x FETCH_SIZE + WRITE_SIZE of separate rocprofv3 --pmc runs of the same workload), or None
@@ -138,7 +145,7 @@ def measured_traffic(kernel, workload):
     entry = wl.get(kernel)
     if entry:
         return entry["hbm_bytes_per_launch"]
-    inst = [e for k, e in wl.items() if isinstance(e, dict) and k.startswith(kernel + "<")]
+    inst = [e for k, e in wl.items() if isinstance(e, dict) and _is_instance(k, kernel)]
     n = sum(e["launches_per_step"] for e in inst)
     return round(sum(e["hbm_bytes_per_launch"] * e["launches_per_step"] for e in inst) / n) if n else None
 
@@ -152,8 +159,7 @@ def measured_mfma_busy(kernel, digest):
             rows = json.load(f)["kernels"]
     except (OSError, ValueError, KeyError):
         return None
-    inst = [r for r in rows if "mfma_busy_frac" in r and (_norm(r["kernel"]) == kernel or
-                                                           _norm(r["kernel"]).startswith(kernel + "<"))]
+    inst = [r for r in rows if "mfma_busy_frac" in r and _is_instance(r["kernel"], kernel)]
     t = sum(r["calls"] * r["avg_us"] for r in inst)
     return round(sum(r["mfma_busy_frac"] * r["calls"] * r["avg_us"] for r in inst) / t, 4) if t else None
 
