@@ -117,6 +117,11 @@ __global__ __launch_bounds__(64 * TH) void bconv_kernel(mgx_conv_desc d, const b
         }
     };
 
+    // biases in LDS: an accumulation starts from the bias of its output channels instead of from zero
+    float* bl = (float*)(xt + 2 * NPIX * 64);
+    if (EPI == 1)
+        for (int i = tid; i < N; i += NTHR) bl[i] = d.nbias > 0 ? bias[i] : 0.f;
+
     long t = blockIdx.x;
     int oc = 0;
     if (t < ntiles) {
@@ -128,15 +133,23 @@ __global__ __launch_bounds__(64 * TH) void bconv_kernel(mgx_conv_desc d, const b
     const float k1 = 1.0f + inv_alpha;
     int cur = 0;
     f32x16 acc[NT];
+    // registers 4g .. 4g+3 of an accumulator tile are output channels 8g + 4h .. 8g + 4h + 3 of chunk nc_
+    auto acc_init = [&](int nc_) {
 #pragma unroll
-    for (int nt = 0; nt < NT; ++nt)
+        for (int g = 0; g < 4; ++g) {
+            f32x4 v = (f32x4){0.f, 0.f, 0.f, 0.f};
+            if (EPI == 1) v = *(const f32x4*)(bl + nc_ * 32 + 8 * g + 4 * h);
 #pragma unroll
-        for (int i = 0; i < 16; ++i) acc[nt][i] = 0.f;
+            for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+                for (int j = 0; j < 4; ++j) acc[nt][4 * g + j] = v[j];
+        }
+    };
+    acc_init(0);
 
     // ---- epilogue of the wave's row of tile t_, output channel chunk nc_ ----
-    // values the epilogue of this step needs from global memory, requested before the MFMA phase so that
-    // their latency is covered by it: the 16 biases of the lane's channels, or the lane's 2 x 32 bytes of `ymul`
-    f32x4 pre_b[4];
+    // what the epilogue of this step needs from global memory (the lane's 2 x 32 bytes of `ymul`) is requested
+    // before the MFMA phase, so that its latency is covered by it
     u32x4 pre_m[NT][2];
     auto epilogue_addr = [&](long t_, int nc_, long& rowoff, unsigned& row_bytes, int& pstride, int& coff, int& w0) {
         long img; int h0;
@@ -148,12 +161,6 @@ __global__ __launch_bounds__(64 * TH) void bconv_kernel(mgx_conv_desc d, const b
         coff = scat ? (nc_ & 1) * 64 + 16 * h : nc_ * 64 + 16 * h;    // the lane's first 16 bytes; the second 32 further
     };
     auto epilogue_prefetch = [&](long t_, int nc_) {
-        if (EPI == 1) {
-#pragma unroll
-            for (int g = 0; g < 4; ++g)         // channels 8h .. 8h+7 and 16+8h .. 16+8h+7 (acc_rows_interleaved)
-                pre_b[g] = d.nbias > 0 ? *(const f32x4*)(bias + nc_ * 32 + 8 * h + 16 * (g >> 1) + 4 * (g & 1))
-                                       : (f32x4){0.f, 0.f, 0.f, 0.f};
-        }
         if (EPI == 2) {
             long rowoff; unsigned row_bytes; int pstride, coff, w0;
             epilogue_addr(t_, nc_, rowoff, row_bytes, pstride, coff, w0);
@@ -171,11 +178,6 @@ __global__ __launch_bounds__(64 * TH) void bconv_kernel(mgx_conv_desc d, const b
         long rowoff; unsigned row_bytes; int pstride, coff, w0;
         epilogue_addr(t_, nc_, rowoff, row_bytes, pstride, coff, w0);
         const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc((void*)(y + rowoff), 0, row_bytes, 0x00020000);
-        float bv[16];
-        if (EPI == 1) {
-#pragma unroll
-            for (int i = 0; i < 16; ++i) bv[i] = pre_b[i >> 2][i & 3];
-        }
         mfma_result_wait();
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
@@ -188,14 +190,14 @@ __global__ __launch_bounds__(64 * TH) void bconv_kernel(mgx_conv_desc d, const b
 #pragma unroll
                     for (int i = 0; i < 16; i += 2) {
                         float y0, y1, d0, d1;
-                        act_bf16(a[i] + bv[i], inv_alpha, k1, y0, d0);
-                        act_bf16(a[i + 1] + bv[i + 1], inv_alpha, k1, y1, d1);
+                        act_bf16(a[i], inv_alpha, k1, y0, d0);
+                        act_bf16(a[i + 1], inv_alpha, k1, y1, d1);
                         o[i >> 1] = bf_pack(y0, y1);
                         dd[i >> 1] = bf_pack(d0, d1);
                     }
                 } else {
 #pragma unroll
-                    for (int i = 0; i < 16; i += 2) o[i >> 1] = bf_pack(a[i] + bv[i], a[i + 1] + bv[i + 1]);
+                    for (int i = 0; i < 16; i += 2) o[i >> 1] = bf_pack(a[i], a[i + 1]);
                 }
             } else if (EPI == 2) {
                 const u32x4 m0 = pre_m[nt][0], m1 = pre_m[nt][1];
@@ -229,7 +231,7 @@ __global__ __launch_bounds__(64 * TH) void bconv_kernel(mgx_conv_desc d, const b
         const bool need_x = has_next && (kchunks > 1 || ocn == 0);
         if (need_x) stage_load(tn, kchunks > 1 ? ocn : 0);
         const bool ep_now = kchunks == 1 || oc == S - 1;
-        if (ep_now) epilogue_prefetch(t, nchunks > 1 ? oc : 0);
+        if (ep_now && EPI == 2) epilogue_prefetch(t, nchunks > 1 ? oc : 0);
         const unsigned char* xb = xt + cur * (NPIX * 64);
         const int kc = kchunks > 1 ? oc : 0, nc = nchunks > 1 ? oc : 0;
         const unsigned char* wb = wl + ((nc * TAPS * (K >> 4) + kc * 2) * 64 + lane) * 16;
@@ -248,10 +250,7 @@ __global__ __launch_bounds__(64 * TH) void bconv_kernel(mgx_conv_desc d, const b
         if (need_x) stage_write(xt + (cur ^ 1) * (NPIX * 64));
         if (ep_now) {
             epilogue(acc, t, nc);
-#pragma unroll
-            for (int nt = 0; nt < NT; ++nt)
-#pragma unroll
-                for (int i = 0; i < 16; ++i) acc[nt][i] = 0.f;
+            acc_init(nchunks > 1 ? ocn : 0);
         }
         __syncthreads();
         if (need_x) cur ^= 1;
@@ -268,7 +267,7 @@ int launch_shape(const mgx_conv_desc& d, const bf16_t* x, const float* w, const 
     const long ntiles = (long)d.nimg * tiles_h * tiles_w;
     if (ntiles <= 0 || ntiles >= (1L << 31)) return MGX_ERR_ARG;
     const unsigned grid = (unsigned)(ntiles < 256 ? ntiles : 256);
-    const int lds = KH * KW * d.cin * d.ngemm * 2 + 2 * npix<KH, KW, TH, NT>() * 64;
+    const int lds = KH * KW * d.cin * d.ngemm * 2 + 2 * npix<KH, KW, TH, NT>() * 64 + d.ngemm * 4;
     if (lds > 160 * 1024) return MGX_ERR_ARG;
     const int epi = ymul != nullptr ? 2 : ((d.nbias > 0 || d.act_alpha > 0.f) ? 1 : 0);
 #define MGX_B(E)                                                                                                     \
@@ -291,7 +290,7 @@ int launch_shape(const mgx_conv_desc& d, const bf16_t* x, const float* w, const 
 template <int KH, int KW>
 int launch_b(const mgx_conv_desc& d, const bf16_t* x, const float* w, const float* bias, bf16_t* y, bf16_t* dact,
              const bf16_t* ymul, hipStream_t st, int gin_w, int scat) {
-    const int lds16 = KH * KW * d.cin * d.ngemm * 2 + 2 * npix<KH, KW, 16, 1>() * 64;
+    const int lds16 = KH * KW * d.cin * d.ngemm * 2 + 2 * npix<KH, KW, 16, 1>() * 64 + d.ngemm * 4;
     bool tall = d.hin >= 16 && d.hin % 16 == 0 && lds16 <= 160 * 1024;
     if (const char* e = getenv("MGX_BCONV_TILE")) tall = e[0] == '1' && lds16 <= 160 * 1024;
     if (tall) return launch_shape<KH, KW, 16, 1>(d, x, w, bias, y, dact, ymul, st, gin_w, scat);

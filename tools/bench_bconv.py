@@ -43,6 +43,8 @@ dd = layer._desc("d", a.n, a.h, a.w)
 for name, f, nbytes in (
         ("fwd+act+dact", lambda: ops.conv_gemm_bf16(fd, x, kd, bd, y, dact=dact, act_alpha=7.0), px * 2 * (a.cin + 2 * a.cout)),
         ("fwd+act", lambda: ops.conv_gemm_bf16(fd, x, kd, bd, y, act_alpha=7.0), px * 2 * (a.cin + a.cout)),
+        ("fwd+bias", lambda: ops.conv_gemm_bf16(fd, x, kd, bd, y, act_alpha=0.0), px * 2 * (a.cin + a.cout)),
+        ("dgrad", lambda: ops.conv_gemm_bf16(dd, y, kd, None, dx), px * 2 * (a.cout + a.cin)),
         ("dgrad*mul", lambda: ops.conv_gemm_bf16(dd, y, kd, None, dx, ymul=mul), px * 2 * (a.cout + 2 * a.cin))):
     ms = timed(f)
     print("%-14s %.3f ms  %6.0f GB/s (algorithmic)  %6.0f TFLOP/s" % (name, ms, nbytes / ms / 1e6, flops / ms / 1e9), flush=True)
