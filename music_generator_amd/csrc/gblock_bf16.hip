@@ -52,7 +52,8 @@ constexpr long PACKB_BYTES = (long)NFB * 1024 + NBIAS * 4;
 
 constexpr int TL_BYTES = 2048;                       // [32 positions][32 rows] bf16 transposition image; two per wave
 constexpr int BUF_BYTES = TAIL_HI * 1024;           // one phase buffer
-constexpr int LDS_BYTES = 4 * 1024 + 2 * BUF_BYTES + 8 * TL_BYTES; // featured fragments + two phase buffers + the
+constexpr int LDS_BIAS = ((NBIAS * 4 + 1023) / 1024) * 1024;      // the float32 biases, copied once per workgroup
+constexpr int LDS_BYTES = 4 * 1024 + 2 * BUF_BYTES + 8 * TL_BYTES + LDS_BIAS; // featured fragments + two phase buffers + the
                                                                 // waves' transposition images of the tape stores
 
 __global__ __launch_bounds__(256) void gblock_pack_bf16_kernel(mgx_gblock_weights w, unsigned char* __restrict__ packb) {
@@ -227,10 +228,16 @@ __global__ __launch_bounds__(256, 1) void gblock_fwd_bf16_kernel(const unsigned 
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int r = lane & 31, h = lane >> 5;
-    const float* bias = (const float*)(packb + (long)NFB * 1024);
     unsigned char* fbuf = lds;                               // featured fragments (4)
     unsigned char* pbuf = lds + 4 * 1024;                    // two phase buffers
     TapeOut tl = {lds + 4 * 1024 + 2 * BUF_BYTES + wv * 2 * TL_BYTES, nullptr, 0, 0, 0};   // this wave's images
+    // biases in LDS: an accumulator tile starts from its bias, 26 times per sub-row; from global memory each
+    // of those loads would stand in front of its MFMAs with an L2 latency (one wave per SIMD: nothing hides it)
+    float* bias = (float*)(lds + 4 * 1024 + 2 * BUF_BYTES + 8 * TL_BYTES);
+    {
+        const float* gbias = (const float*)(packb + (long)NFB * 1024);
+        for (int i = threadIdx.x; i < NBIAS; i += 256) bias[i] = gbias[i];
+    }
 
     // phase q of a sub-row: fragments [phase_f0(q), + phase_n(q))
     auto phase_f0 = [](int q) { return q < 6 ? FB_BR + q * BRF : (q == 6 ? FB_T : FB_T + TAIL_LO); };

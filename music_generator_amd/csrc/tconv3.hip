@@ -153,9 +153,16 @@ __global__ __launch_bounds__(512, 2) void tconv3_kernel(mgx_conv_desc d, const f
     __syncthreads();
     const float inv_alpha = d.act_alpha > 0.f ? 1.0f / d.act_alpha : 0.f;
     int cur = 0;
+    // An accumulation starts from the bias of the lane's output channel (column r of chunk nc) instead of from
+    // zero: the up to four values are loaded once, before the tile loop (a load inside the epilogue stands in
+    // front of it with its whole latency, a quarter of the tile time of the 2x2 and 1x1 convolutions).
+    float bl4[4];
+#pragma unroll
+    for (int j = 0; j < 4; ++j) bl4[j] = (d.nbias > 0 && j < nchunks) ? bias[j * 32 + r] : 0.f;
+    auto bias_of = [&](int nc_) { return nc_ == 0 ? bl4[0] : (nc_ == 1 ? bl4[1] : (nc_ == 2 ? bl4[2] : bl4[3])); };
     f32x16 acc;
 #pragma unroll
-    for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+    for (int i = 0; i < 16; ++i) acc[i] = bl4[0];
 
     // ---- epilogue of row wv of tile t_, output channels [32 nc, 32 nc + 32) ----
     // loads (accumulate), arithmetic and stores run in separate sweeps: 16 independent memory
@@ -167,7 +174,6 @@ __global__ __launch_bounds__(512, 2) void tconv3_kernel(mgx_conv_desc d, const f
     const int wrow = TH == 8 ? wvs : (wvs & 3), wcol = TH == 8 ? 0 : (wvs >> 2) * 32;     // the wave's row and first column in the tile
     auto epilogue = [&](const f32x16& a, long t_, int oc_) {
         const int n = (nchunks > 1 ? oc_ : 0) * 32 + r;
-        const float bv = d.nbias > 0 ? bias[n] : 0.f;
         long img; int h0, w0;
         tile_of(t_, img, h0, w0);
         const int nc_ = nchunks > 1 ? oc_ : 0;
@@ -181,7 +187,7 @@ __global__ __launch_bounds__(512, 2) void tconv3_kernel(mgx_conv_desc d, const f
         const bool act = d.act_alpha > 0.f;
         float v[16], der[16];
 #pragma unroll
-        for (int reg = 0; reg < 16; ++reg) v[reg] = a[reg] + bv;
+        for (int reg = 0; reg < 16; ++reg) v[reg] = a[reg];
         if (act) {
 #pragma unroll
             for (int reg = 0; reg < 16; ++reg) {
@@ -273,8 +279,9 @@ __global__ __launch_bounds__(512, 2) void tconv3_kernel(mgx_conv_desc d, const f
             } else {
                 epilogue(acc, t, oc);
             }
+            const float b_next = bias_of(nchunks > 1 ? ocn : 0);
 #pragma unroll
-            for (int reg = 0; reg < 16; ++reg) acc[reg] = 0.f;
+            for (int reg = 0; reg < 16; ++reg) acc[reg] = b_next;
         }
         __syncthreads();
         if (need_x && NBUF == 2) cur ^= 1;

@@ -217,6 +217,9 @@ __global__ __launch_bounds__(256, 1) void wino3_kernel(mgx_conv_desc d, const fl
     }
     const float* ubase = ul + h * 128 + r * 4;
     const float inv_alpha = d.act_alpha > 0.f ? 1.0f / d.act_alpha : 0.f;
+    // the lane's bias: with one output channel block it does not depend on the tile (a load inside the epilogue
+    // has its whole latency exposed: one wave per SIMD, nothing else to run)
+    const float bias_lane = (NB == 1 && d.nbias > 0) ? bias[r] : 0.f;
     const unsigned out_row_bytes = (unsigned)W * (unsigned)OSTR * 4u;
 
     long t = blockIdx.x;
@@ -359,7 +362,7 @@ __global__ __launch_bounds__(256, 1) void wino3_kernel(mgx_conv_desc d, const fl
                 asm volatile("s_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 15\n\ts_nop 7" ::: "memory");
                 if (h0 + 4 * wv < H) {                     // H is a multiple of 4: a wave is all in or all out
                     const unsigned vbase = (unsigned)(((w0 + 8 * h) * OSTR + r) * 4);
-                    const float bv = d.nbias > 0 ? bias[nb * 32 + r] : 0.f;
+                    const float bv = NB == 1 ? bias_lane : (d.nbias > 0 ? bias[nb * 32 + r] : 0.f);
                     const f32x2 bv2 = {bv, bv}, ia2 = {inv_alpha, inv_alpha};
                     // Output transform Y[a][b] = sum over (xi, nu) of At[a][xi] At[b][nu] M[xi][nu] with
                     // At = [1 1 1 0; 0 1 -1 -1]: every accumulator tile is copied out of the accumulation
