@@ -123,6 +123,14 @@ __device__ __forceinline__ void init_bias(f32x16& acc, const float* __restrict__
     }
 }
 
+// MFMA into an accumulator tile pinned to the accumulation registers (the file is otherwise built with MFMA results
+// in vector registers, where the conversions read them): for the eight tiles that sum the six branches, which are
+// only ever touched by MFMAs until the sub-row's tail, so that 128 vector registers stay free for the operand
+// reads to run ahead.  The compiler does not see this instruction: mfma_result_wait() before the tile is read.
+__device__ __forceinline__ void mfma_bf16_pinned(f32x16& c, u32x4 a, u32x4 b) {
+    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
+}
+
 // B operand of the next layer: k-step s = registers 8s .. 8s+7 as bf16
 struct BTile { u32x4 k[2]; };
 __device__ __forceinline__ BTile to_b(const f32x16& a) {
@@ -326,13 +334,17 @@ __global__ __launch_bounds__(256, 1) void gblock_fwd_bf16_kernel(const unsigned 
                         for (int it = 0; it < 2; ++it)
 #pragma unroll
                             for (int ks = 0; ks < 2; ++ks)
-                                S[b][ot] = mfma_bf16(frag(wb, FB_D2 + (ot * 2 + it) * 2 + ks, lane), o3b[it].k[ks], S[b][ot]);
+                                if (SAVE)       // the taped kernel is short of vector registers (tape stores): measured
+                                    mfma_bf16_pinned(S[b][ot], frag(wb, FB_D2 + (ot * 2 + it) * 2 + ks, lane), o3b[it].k[ks]);
+                                else            // 380 -> 482 TFLOP/s pinned; the plain forward loses with it (831 -> 813)
+                                    S[b][ot] = mfma_bf16(frag(wb, FB_D2 + (ot * 2 + it) * 2 + ks, lane), o3b[it].k[ks], S[b][ot]);
                 }
                 __syncthreads();                      // waits for this wave's DMA, then for every wave
                 par ^= 1;
             }
             // ---- Dense tail: Dense(256) in 8 chunks of 32 rows, each consumed at once by Dense(64) ----
             BTile Sb[2][4];
+            if (SAVE) mfma_result_wait();
 #pragma unroll
             for (int b = 0; b < 2; ++b)
 #pragma unroll
