@@ -300,6 +300,16 @@ int64_t mgx_conv_wgrad_bf16_workspace(const mgx_conv_desc* d);
 int mgx_conv_wgrad_bf16(const mgx_conv_desc* d, const void* x, const void* g, float* dw, float* dbias,
                         void* workspace, int64_t workspace_bytes, void* stream);
 
+/* Two consecutive Conv2D + SoftRectifier layers of a discriminator block (trainer/models.py:259-276) in one launch,
+ * for forward passes that keep no tape: Conv2D(32, 3x3, 'same') + SoftRectifier(alpha_a), then Conv2D(32, kb x kb,
+ * 'same', kb = 3 or 2) + SoftRectifier(alpha_b), 32 -> 32 -> 32 channels.  x and y are bf16 NHWC (nimg, h, w, 32);
+ * wa / wb the float32 Keras kernels (3, 3, 32, 32) / (kb, kb, 32, 32), ba / bb the float32 biases.  The first
+ * layer's output stays in LDS; results are bit-identical to two calls of mgx_conv_gemm_bf16.  Needs h >= 16
+ * (mgx_conv_pair_bf16_supported). */
+int mgx_conv_pair_bf16_supported(int64_t nimg, int h, int w, int kb);
+int mgx_conv_pair_bf16(int64_t nimg, int h, int w, const void* x, const float* wa, const float* ba, float alpha_a,
+                       const float* wb, const float* bb, float alpha_b, int kb, void* y, void* stream);
+
 /* From-audio 1x1 convolution (models.py:256): x float32 (npos, 2) -> y bf16 (npos, 128) with kernel w
  * (2,128) and bias (128) float32, optional tanh(v)+v/alpha epilogue (act_alpha > 0) and derivative
  * store (dact, bf16, may be NULL).  Its weight gradient (dw (2,128), db (128) ADDED to; g = gradient

@@ -178,7 +178,8 @@ __global__ __launch_bounds__(64 * TH) void bconv_kernel(mgx_conv_desc d, const b
         long rowoff; unsigned row_bytes; int pstride, coff, w0;
         epilogue_addr(t_, nc_, rowoff, row_bytes, pstride, coff, w0);
         const __amdgpu_buffer_rsrc_t ry = __builtin_amdgcn_make_buffer_rsrc((void*)(y + rowoff), 0, row_bytes, 0x00020000);
-        mfma_result_wait();
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) mfma_result_wait(av[nt]);
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt) {
             f32x16& a = av[nt];

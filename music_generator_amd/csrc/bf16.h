@@ -34,6 +34,11 @@ __device__ __forceinline__ f32x16 mfma_bf16(u32x4 a, u32x4 b, f32x16 c) {
 // Wait states between the last MFMA that writes an accumulator and an inline-asm statement that reads it
 // (the compiler pads vector-ALU readers it schedules itself, but nothing inside or in front of asm).
 __device__ __forceinline__ void mfma_result_wait() { asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 3"); }
+// The same, tied to the accumulator it protects: without a data dependency the compiler is free to schedule
+// the wait in front of the MFMAs it is meant to follow.
+__device__ __forceinline__ void mfma_result_wait(f32x16& acc) {
+    asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 3" : "+v"(acc));
+}
 
 // After this exchange between lanes l and l^32, lane (r, h) holds rows 8h .. 8h+7 of column r of a 32x32
 // accumulator tile in a[0..7] and rows 16+8h .. 16+8h+7 in a[8..15]: as bf16 the two lanes of a column hold

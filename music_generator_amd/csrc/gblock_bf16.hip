@@ -344,7 +344,10 @@ __global__ __launch_bounds__(256, 1) void gblock_fwd_bf16_kernel(const unsigned 
             }
             // ---- Dense tail: Dense(256) in 8 chunks of 32 rows, each consumed at once by Dense(64) ----
             BTile Sb[2][4];
-            if (SAVE) mfma_result_wait();
+            if (SAVE)        // tied to the eight tiles: the copies out of them must not be scheduled in front of the wait
+                asm volatile("s_nop 7\n\ts_nop 7\n\ts_nop 3"
+                             : "+a"(S[0][0]), "+a"(S[0][1]), "+a"(S[0][2]), "+a"(S[0][3]), "+a"(S[1][0]), "+a"(S[1][1]),
+                               "+a"(S[1][2]), "+a"(S[1][3]));
 #pragma unroll
             for (int b = 0; b < 2; ++b)
 #pragma unroll

@@ -349,6 +349,13 @@ class Model:
         return t
 
     # -- execution --
+    # True: two consecutive convolution + activation steps of a tape-free bf16 pass run as one launch with the
+    # intermediate in LDS (mgx_conv_pair_bf16; bit-identical results).  Off by default: measured 25 % SLOWER than
+    # the two launches it replaces (0.61 against 2 x 0.24 ms on the stage-3 step's mix): the convolution kernels
+    # are bound by instruction issue (MFMA + activation + LDS reads), not by the HBM traffic the fusion saves,
+    # and the fused tile does 1.22x the work of both layers with two more barriers.
+    use_conv_pairs = False
+
     def forward(self, x, save: bool = False):
         """Run the plan.  Returns (y, tape); tape is None unless save=True."""
         x = self._to_device(x)
@@ -362,8 +369,29 @@ class Model:
         last_use = self._last_use if plan is self._plan else self._last_use_infer
         if save:
             tape.plan = plan
+        producer, n_consumers = self._plan_links(plan)
+        skip = -1
         for i, op in enumerate(plan):
+            if i == skip:
+                continue
             xs = [vals[id(t)] for t in op.inputs]
+            # two consecutive convolution + activation steps whose intermediate nothing else reads run as one
+            # launch when no tape is kept (bf16 path; the intermediate stays in LDS)
+            if (not save and Model.use_conv_pairs and not isinstance(op, _FusedOp) and op.act_node is not None
+                    and i + 1 < len(plan)):
+                nxt = plan[i + 1]
+                if (not isinstance(nxt, _FusedOp) and nxt.act_node is not None and len(nxt.inputs) == 1
+                        and nxt.inputs[0] is op.output and n_consumers.get(id(op.output), 0) == 1
+                        and op.output is not self.output):
+                    from .layers import conv_pair_eligible, conv_pair_forward
+                    if conv_pair_eligible(op.node.layer, nxt.node.layer, xs[0]):
+                        vals[id(nxt.output)] = conv_pair_forward(op.node.layer, op.act_node.layer.alpha_value,
+                                                                 nxt.node.layer, nxt.act_node.layer.alpha_value, xs[0])
+                        for t in op.inputs:
+                            if last_use.get(id(t)) == i and t is not self.output:
+                                vals.pop(id(t), None)
+                        skip = i + 1
+                        continue
             if isinstance(op, _FusedOp):
                 if save:
                     vals[id(op.output)], saved = op.group.run_save(xs[0])

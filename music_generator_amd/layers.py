@@ -185,6 +185,28 @@ class _Contraction(Layer):
         return [(dx, True)]
 
 
+def conv_pair_eligible(a, b, x) -> bool:
+    """Layers a, b (each followed by a SoftRectifier) as one launch of the pair kernel: a is Conv2D(32, 3x3, same),
+    b Conv2D(32, 3x3 or 2x2, same), both on 32 channels, bf16 input of at least 16 rows, bf16 precision on."""
+    if not (K.bf16_enabled() and isinstance(a, Conv2D) and isinstance(b, Conv2D)):
+        return False
+    if x.dim() != 4 or x.dtype != torch.bfloat16 or x.shape[-1] != 32:
+        return False
+    for l in (a, b):
+        if l.padding != "same" or l.strides != (1, 1) or l.filters != 32 or l.cin != 32:
+            return False
+    if a.kernel_size != (3, 3) or b.kernel_size not in ((3, 3), (2, 2)):
+        return False
+    return ops.conv_pair_bf16_supported(x.shape[0], x.shape[1], x.shape[2], b.kernel_size[0])
+
+
+def conv_pair_forward(a, alpha_a, b, alpha_b, x):
+    y = K.empty(tuple(x.shape), dtype=torch.bfloat16)
+    ops.conv_pair_bf16(x, a.kernel.value(), a.bias.value(), alpha_a, b.kernel.value(), b.bias.value(), alpha_b,
+                       b.kernel_size[0], y)
+    return y
+
+
 class _CastSaved(tuple):
     """(x, dact) of a float32 contraction whose input arrived as bf16 and was cast: the data-gradient goes
     back as bf16."""

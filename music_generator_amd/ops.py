@@ -512,6 +512,26 @@ def conv_gemm_bf16(d: ConvDesc, x, w, bias, y, dact=None, ymul=None, act_alpha=0
                       _conv_bytes_bf16(d, 1, 1 + (1 if dact is not None else 0) + (1 if ymul is not None else 0)))
 
 
+def conv_pair_bf16_supported(n, h, w, kb) -> bool:
+    return bool(_lib().mgx_conv_pair_bf16_supported(int(n), int(h), int(w), int(kb)))
+
+
+def conv_pair_bf16(x, wa, ba, alpha_a, wb, bb, alpha_b, kb, y):
+    """mgx_conv_pair_bf16: Conv2D(32, 3x3, same) + SoftRectifier then Conv2D(32, kb x kb, same) + SoftRectifier on
+    a bf16 (n, h, w, 32) tensor, no tape."""
+    n, h, w, c = x.shape
+    if c != 32 or tuple(y.shape) != (n, h, w, 32) or x.dtype != torch.bfloat16 or y.dtype != torch.bfloat16:
+        raise MgxError("conv_pair_bf16: x and y must be bf16 (n, h, w, 32) tensors of one shape")
+    if wa.numel() != 9 * 1024 or wb.numel() != kb * kb * 1024 or ba.numel() != 32 or bb.numel() != 32:
+        raise MgxError("conv_pair_bf16: kernels must be (3,3,32,32) and (kb,kb,32,32), biases (32,)")
+    e0 = PROFILER.start() if PROFILER is not None else None
+    check(_lib().mgx_conv_pair_bf16(n, h, w, _pb(x), _p(wa), _p(ba), float(alpha_a), _p(wb), _p(bb), float(alpha_b),
+                                    int(kb), _pb(y), K.stream_ptr()), "mgx_conv_pair_bf16")
+    if e0 is not None:
+        px = n * h * w
+        PROFILER.stop("bpair_kernel<%d>" % kb, 2.0 * (9 + kb * kb) * 1024 * px, e0, px * 128)
+
+
 def conv_wgrad_bf16(d: ConvDesc, x, g, dw, dbias):
     xe, ye, we = _conv_sizes(d)
     if x.numel() != xe or g.numel() != ye or dw.numel() < we:

@@ -574,3 +574,63 @@ def test_bf16_full_resolution_step_properties(bf16_precision):
         assert gan.actual_step == 4 and gan.d_optimizer.iterations == 1 and gan.g_optimizer.iterations == 1
     finally:
         FusedGroup.side_budget_bytes = None
+
+
+@pytest.mark.parametrize("h,w,n,kb", [(16, 64, 1, 3), (16, 31, 2, 2), (20, 45, 2, 3), (32, 100, 3, 2), (48, 333, 1, 3),
+                                      (17, 30, 1, 3), (64, 500, 2, 2)])
+def test_bf16_conv_pair_equals_two_launches(h, w, n, kb):
+    """mgx_conv_pair_bf16 (two convolution + activation layers in one launch, the intermediate in LDS) against two
+    launches of mgx_conv_gemm_bf16: the same MFMAs on the same bf16 values in the same order, so the outputs
+    must be equal bit for bit, on ragged tiles (rows not a multiple of 17 - kb, columns not of 33 - kb), at
+    the image borders (zero padding of BOTH layers) and across images."""
+    M.clear_session()
+    a = L.Conv2D(32, (3, 3), padding="same", kernel_initializer="he_normal")
+    b = L.Conv2D(32, (kb, kb), padding="same", kernel_initializer="he_normal")
+    a(Input(shape=(h, w, 32)))
+    b(Input(shape=(h, w, 32)))
+    rng = np.random.default_rng(h * 100 + w + kb)
+    for layer in (a, b):
+        layer.bias.assign(rng.uniform(-0.3, 0.3, (32,)).astype(np.float32))
+    x = _dev_b(rng.uniform(-1, 1, (n, h, w, 32)))
+    alpha_a, alpha_b = 7.0, 80000.0
+    mid = torch.empty((n, h, w, 32), dtype=torch.bfloat16, device="cuda")
+    want = torch.empty_like(mid)
+    ops.conv_gemm_bf16(a._desc("f", n, h, w), x, a.kernel.value(), a.bias.value(), mid, act_alpha=alpha_a)
+    ops.conv_gemm_bf16(b._desc("f", n, h, w), mid, b.kernel.value(), b.bias.value(), want, act_alpha=alpha_b)
+    assert ops.conv_pair_bf16_supported(n, h, w, kb)
+    got = torch.full_like(want, float("nan"))
+    ops.conv_pair_bf16(x, a.kernel.value(), a.bias.value(), alpha_a, b.kernel.value(), b.bias.value(), alpha_b, kb, got)
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(got.float()).all()), "positions left unwritten"
+    diff = (got.float() - want.float()).abs()
+    where = np.unravel_index(int(diff.argmax()), tuple(diff.shape))
+    assert torch.equal(got.view(torch.int16), want.view(torch.int16)), "max abs difference %.3e at %s" % (float(diff.max()), where)
+
+
+def test_bf16_discriminator_forward_with_and_without_pairs(bf16_precision):
+    """A tape-free discriminator forward (the metric passes of the step) with the pair kernel (Model.use_conv_pairs,
+    off by default: it is slower than the launches it replaces) against the same forward layer by layer:
+    bit-identical logits; with a tape the pair kernel is not used at all."""
+    from music_generator_amd.graph import Model
+    d, g, comp, W = _build(4)
+    model = d[3][1]
+    real, _ = R.synthetic_inputs(3, 4, seed=2)
+    x = torch.from_numpy(real).cuda()
+    calls = []
+    orig = ops.conv_pair_bf16
+    ops.conv_pair_bf16 = lambda *a, **k: (calls.append(1), orig(*a, **k))[1]
+    try:
+        Model.use_conv_pairs = True
+        y1 = model(x).clone()
+        n_pairs = len(calls)
+        Model.use_conv_pairs = False
+        y0 = model(x).clone()
+        assert len(calls) == n_pairs
+        Model.use_conv_pairs = True
+        model.forward(x, save=True)
+        assert len(calls) == n_pairs
+    finally:
+        Model.use_conv_pairs = False
+        ops.conv_pair_bf16 = orig
+    assert n_pairs >= 3, n_pairs
+    assert torch.equal(y0, y1), (y0, y1)
