@@ -74,15 +74,23 @@ __global__ __launch_bounds__(64 * TH) void bconv_kernel(mgx_conv_desc d, const b
     }
 
     // ---- input tile staging: thread t moves 16-byte piece #(t + 512 i) = (position, quad) ----
+    // Tile order.  Workgroup b runs on XCD b % 8 (each XCD has its own L2), and the halo of a tile is input its
+    // neighbours read too: within every full round of 256 tiles the 32 workgroups of an XCD take 32 CONSECUTIVE
+    // tiles, and consecutive tiles are vertical neighbours first (column-major inside an image), so that the
+    // halo rows and most halo columns of a tile are found in the XCD's L2 instead of being fetched again.
     auto tile_of = [&](long t, long& img, int& h0, int& w0) {
         const unsigned per_img = (unsigned)(tiles_h * tiles_w);
-        const unsigned tu = (unsigned)t;
+        unsigned tu = (unsigned)t;
+        if (gridDim.x == 256) {
+            const unsigned round = tu >> 8, b = tu & 255u;
+            if ((long)(round + 1) * 256 <= ntiles) tu = (round << 8) + (b & 7u) * 32u + (b >> 3);
+        }
         const unsigned im = tu / per_img;
         const unsigned rem = tu - im * per_img;
-        const unsigned th = rem / (unsigned)tiles_w;
+        const unsigned tw = rem / (unsigned)tiles_h;
         img = im;
-        h0 = (int)th * TH;
-        w0 = (int)(rem - th * tiles_w) * TW;
+        h0 = (int)(rem - tw * tiles_h) * TH;
+        w0 = (int)tw * TW;
     };
     const int q4 = tid & 3;
     const unsigned band_bytes = gin_w > 0 ? (unsigned)(2 * IH) * gin_w * 64u : (unsigned)IH * W * d.cin * 2u;

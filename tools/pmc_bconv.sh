@@ -6,8 +6,7 @@ out=$root/gpurun_out/${1:-pmc_bconv}
 mkdir -p "$out"
 cd /tmp && export TMPDIR=/tmp
 i=0
-for pass in "SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_MISC SQ_ACTIVE_INST_SCA SQ_ACTIVE_INST_LDS" \
-            "SQ_WAVE_CYCLES SQ_ACTIVE_INST_VMEM SQ_ACTIVE_INST_FLAT SQ_INSTS_SALU SQ_INSTS_VALU SQ_INSTS_VALU_TRANS_F32 SQ_INSTS_LDS SQ_VALU_MFMA_COEXEC_CYCLES"; do
+for pass in "FETCH_SIZE" "WRITE_SIZE"; do
     i=$((i+1))
     echo "pass $i: $pass"
     timeout -s KILL 120 rocprofv3 --pmc $pass --output-format csv -d "$out/p$i" -- python3 "$root/tools/bench_bconv.py" --reps 1 > /dev/null 2> "$out/p$i.log"
