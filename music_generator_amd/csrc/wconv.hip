@@ -117,28 +117,26 @@ __global__ __launch_bounds__(256, 1) void wino3_kernel(mgx_conv_desc d, const fl
         }
     };
 
-    // ---- tile walk in scalar registers: (image, tile row, tile column) advance by the grid size ----
-    WTile dstep, cur;
-    {
+    // ---- tile order, in scalar registers.  Workgroup b runs on XCD b % 8 (each XCD has its own L2) and the
+    //      18 x 34 halo tile of a 16 x 32 output tile overlaps its neighbours': within every full round of 256
+    //      tiles the 32 workgroups of an XCD take 32 CONSECUTIVE tiles, and consecutive tiles are vertical
+    //      neighbours first (column-major inside an image), so that halo rows and columns are found in the
+    //      XCD's L2 instead of being fetched from HBM again (measured before: 1.43x the input bytes fetched) ----
+    auto tile_at = [&](long t_) {
         const unsigned per_img = (unsigned)(tiles_h * tiles_w);
-        const unsigned g = gridDim.x, b = blockIdx.x;
-        dstep.img = (int)(g / per_img);
-        unsigned rem = g - (unsigned)dstep.img * per_img;
-        dstep.th = (int)(rem / (unsigned)tiles_w);
-        dstep.tw = (int)(rem - (unsigned)dstep.th * tiles_w);
-        cur.img = (int)(b / per_img);
-        rem = b - (unsigned)cur.img * per_img;
-        cur.th = (int)(rem / (unsigned)tiles_w);
-        cur.tw = (int)(rem - (unsigned)cur.th * tiles_w);
-    }
-    auto advance = [&](WTile t) {
-        t.tw += dstep.tw;
-        if (t.tw >= tiles_w) t.tw -= tiles_w, ++t.th;
-        t.th += dstep.th;
-        if (t.th >= tiles_h) t.th -= tiles_h, ++t.img;
-        t.img += dstep.img;
-        return t;
+        unsigned tu = (unsigned)t_;
+        if (gridDim.x == 256) {
+            const unsigned round = tu >> 8, b = tu & 255u;
+            if ((long)(round + 1) * 256 <= ntiles) tu = (round << 8) + (b & 7u) * 32u + (b >> 3);
+        }
+        WTile w_;
+        w_.img = (int)(tu / per_img);
+        const unsigned rem = tu - (unsigned)w_.img * per_img;
+        w_.tw = (int)(rem / (unsigned)tiles_h);
+        w_.th = (int)(rem - (unsigned)w_.tw * tiles_h);
+        return w_;
     };
+    WTile cur = tile_at(blockIdx.x);
 
     // ---- input tile global -> registers -> LDS.  Wave w moves tile rows w, w+4, ...; a row is three
     //      instructions of 16 position slots (the third half-masked).  Lane l of an instruction
@@ -242,7 +240,7 @@ __global__ __launch_bounds__(256, 1) void wino3_kernel(mgx_conv_desc d, const fl
     asm volatile("" ::: "memory");
 
     while (t < ntiles) {
-        const WTile nxt = advance(cur);
+        const WTile nxt = tile_at(t + gridDim.x < ntiles ? t + gridDim.x : t);
         const bool next_tile = t + gridDim.x < ntiles;
         // The MFMAs are asm statements with the accumulator tied to the accumulation registers: the
         // compiler's own choice moves a 256-register accumulator set into vector registers as soon
