@@ -94,15 +94,22 @@ __global__ __launch_bounds__(512, 2) void tconv3_kernel(mgx_conv_desc d, const f
     // out-of-range offset, for which the hardware returns zeros - no clamping, no selects, no
     // 64-bit address arithmetic per element.
     const int c4 = tid & 7;
+    // Tile order: workgroup b runs on XCD b % 8 (own L2); within every full round of 256 tiles the 32
+    // workgroups of an XCD take 32 consecutive tiles, vertical neighbours first (column-major inside an
+    // image), so that the halo of a tile is found in the XCD's L2 instead of being fetched from HBM again.
     auto tile_of = [&](long t, long& img, int& h0, int& w0) {
         const unsigned per_img = (unsigned)(tiles_h * tiles_w);
-        const unsigned tu = (unsigned)t;                    // ntiles < 2^31 (checked by the launcher)
+        unsigned tu = (unsigned)t;                          // ntiles < 2^31 (checked by the launcher)
+        if (gridDim.x == 256) {
+            const unsigned round = tu >> 8, b = tu & 255u;
+            if ((long)(round + 1) * 256 <= ntiles) tu = (round << 8) + (b & 7u) * 32u + (b >> 3);
+        }
         const unsigned im = tu / per_img;
         const unsigned rem = tu - im * per_img;
-        const unsigned th = rem / (unsigned)tiles_w;
+        const unsigned tw = rem / (unsigned)tiles_h;
         img = im;
-        h0 = (int)th * TH;
-        w0 = (int)(rem - th * tiles_w) * TW;
+        h0 = (int)(rem - tw * tiles_h) * TH;
+        w0 = (int)tw * TW;
     };
     const unsigned band_bytes = gin_w > 0 ? (unsigned)(2 * IH) * gin_w * 32u * 4u : (unsigned)IH * W * d.cin * 4u;
     int rel[SITER], tyx[SITER];          // byte offset of the element inside the tile window; (ty << 16) | tx
