@@ -145,14 +145,58 @@ def bf16_enabled() -> bool:
     return _precision[0] == "bfloat16"
 
 
-_workspace: Dict[int, torch.Tensor] = {}
+_workspace: Dict[Tuple[int, int], torch.Tensor] = {}
+
+# Lane 0 is the stream the caller made current; lane 1 is the device's second stream, on which WGAN's step
+# runs the pass over the real batch beside the pass over the generated one when a batch is too small to fill
+# the chip.  Scratch buffers are per lane: the kernels of one lane are ordered by its stream, the two lanes
+# are not ordered against each other between fork() and join().
+_lane = [0]
+_lane_streams: Dict[int, "torch.cuda.Stream"] = {}
+
+
+class _SideLane:
+    """`with fork() as lane:` enqueues on the second stream, after everything enqueued so far on the current
+    one; `lane.join()` (called outside the block) makes the current stream wait for that work.  Also valid
+    under HIP graph capture, where it becomes a fork / join of the captured graph."""
+
+    def __init__(self):
+        dev = device()
+        key = dev.index or 0
+        st = _lane_streams.get(key)
+        if st is None:
+            st = torch.cuda.Stream(device=dev)
+            _lane_streams[key] = st
+        self.stream = st
+        self._ctx = None
+
+    def __enter__(self):
+        if _lane[0] != 0:
+            raise RuntimeError("the second lane cannot be forked from itself")
+        self.stream.wait_stream(torch.cuda.current_stream())
+        self._ctx = torch.cuda.stream(self.stream)
+        self._ctx.__enter__()
+        _lane[0] = 1
+        return self
+
+    def __exit__(self, *exc):
+        _lane[0] = 0
+        ctx, self._ctx = self._ctx, None
+        return ctx.__exit__(*exc)
+
+    def join(self):
+        torch.cuda.current_stream().wait_stream(self.stream)
+
+
+def fork() -> _SideLane:
+    return _SideLane()
 
 
 def workspace(nbytes: int) -> torch.Tensor:
-    """A reusable scratch buffer of at least `nbytes` on the current device.  All kernels run on
-    one stream, so consecutive users are ordered."""
+    """A reusable scratch buffer of at least `nbytes` on the current device, one per lane: the kernels
+    of a lane run on one stream, so its consecutive users are ordered."""
     dev = device()
-    key = dev.index or 0
+    key = (dev.index or 0, _lane[0])
     cur = _workspace.get(key)
     if cur is None or cur.numel() < nbytes:
         cur = None
@@ -163,7 +207,7 @@ def workspace(nbytes: int) -> torch.Tensor:
     return cur
 
 
-_side: Dict[int, list] = {}
+_side: Dict[Tuple[int, int], list] = {}
 
 
 def side_buffers(nfloats: int):
@@ -171,7 +215,7 @@ def side_buffers(nfloats: int):
     the bounded side buffers of a re-computing fused backward.  Kept out of the caching allocator
     so that their memory is not carved up between two uses."""
     dev = device()
-    key = dev.index or 0
+    key = (dev.index or 0, _lane[0])
     cur = _side.get(key)
     if cur is None or cur[0].numel() < nfloats:
         _side.pop(key, None)

@@ -554,6 +554,9 @@ class WGAN:
         # batch order) for comparison against a reference; off by default (one gather per step)
         self.keep_logits = False
         self.last_logits = None
+        # None (default): batches of up to OVERLAP_AUTO_BATCH samples run every discriminator pass over the real
+        # batch on a second stream beside the pass over the generated batch (see _overlap); True / False force it
+        self.overlap_passes = None
         self._graphs: Dict = {}
         self._scalars = None                  # device [alpha, lr_t of D, lr_t of G] while capturing
         self._mb_cache: Dict = {}
@@ -643,8 +646,16 @@ class WGAN:
         z = self._draw(n)
         sums = K.zeros((2,))
         for idx in batches:
+            lane = real_logits = None
+            if real_sum is None and self._overlap(n):
+                lane = K.fork()
+                with lane:
+                    real_logits = D(self._take(real, idx)).view(-1)
             fake_logits = D(G(self._take(z, idx)))
-            real_logits = D(self._take(real, idx)).view(-1) if real_sum is None else None
+            if lane is not None:
+                lane.join()
+            elif real_sum is None:
+                real_logits = D(self._take(real, idx)).view(-1)
             ops.logit_sums(fake_logits.view(-1), real_logits, sums, accumulate=True)
         if real_sum is not None:
             sums[1:2].copy_(real_sum)
@@ -671,6 +682,16 @@ class WGAN:
         return out
 
     GRAPH_AUTO_BATCH = 16
+    OVERLAP_AUTO_BATCH = 16
+
+    def _overlap(self, n) -> bool:
+        """Whether the discriminator passes over the real batch run on the second stream beside the passes
+        over the generated batch: by default for whole batches small enough to leave the chip idle."""
+        if self.dist is not None or self.micro_batch or ops.PROFILER is not None:
+            return False
+        if self.overlap_passes is not None:
+            return bool(self.overlap_passes)
+        return n <= self.OVERLAP_AUTO_BATCH
 
     def _graph_wanted(self, real) -> bool:
         if self.use_graph is not None:
@@ -712,7 +733,7 @@ class WGAN:
         # a graph is valid for one batch shape, one set of step-shaping options and one generation of the
         # scratch buffers whose addresses its launches carry
         key = (tuple(real.shape), self.micro_batch, self.generator_chunk, self.reuse_real_logits,
-               FusedGroup.side_budget_bytes, K.precision())
+               FusedGroup.side_budget_bytes, K.precision(), self._overlap(real.shape[0]))
         entry = self._graphs.get(key)
         alpha = self._fade_alpha()
         if entry is None:                       # first sight of this shape: ordinary step, caches warm up
@@ -781,11 +802,29 @@ class WGAN:
             for bi, idx in enumerate(batches):
                 zb, rb = self._take(z, idx), self._take(real, idx)
                 ones = self._ones(rb.shape[0])
+                lane = None
+                if self._overlap(n):
+                    # a small batch leaves most of the chip idle in every launch: the pass over the real batch
+                    # (its own gradient buffer, its own scratch) runs on the second stream beside the pass
+                    # over the generated batch; same kernels, same results
+                    lane = K.fork()
+                    with lane:
+                        real_logits, tape = D.forward(rb, save=True)
+                        D.bind_grads(1)
+                        D.backward(tape, ones, need_input_grad=False)
+                        del tape
                 fake, _ = G.forward(zb, save=False)
                 fake_logits, tape = D.forward(fake, save=True)
                 del fake
                 D.bind_grads(0)
                 D.backward(tape, ones, need_input_grad=False)
+                if lane is not None:
+                    del tape
+                    lane.join()
+                    ops.logit_sums(fake_logits.view(-1), real_logits.view(-1), sums, accumulate=True)
+                    if kept is not None:
+                        kept.append((idx, fake_logits.view(-1).clone(), real_logits.view(-1).clone()))
+                    continue
                 if self.dist is not None and bi == len(batches) - 1:
                     # the fake-pass gradient sums are final: their all-reduce runs on RCCL's stream
                     # beside the real pass of this micro-batch (the combination below is linear, so
@@ -838,6 +877,11 @@ class WGAN:
             zb, rb = self._take(z, idx), self._take(real, idx)
             nb = zb.shape[0]
             chunk = self.generator_chunk if (self.generator_chunk and self.generator_chunk < nb) else None
+            lane = real_logits = None
+            if real_sum is None and self._overlap(n):
+                lane = K.fork()
+                with lane:
+                    real_logits = D(rb).view(-1)
             gen, tape_g = G.forward(zb, save=chunk is None)
             gen_logits, tape_d = D.forward(gen, save=True)
             del gen
@@ -859,7 +903,10 @@ class WGAN:
                 # step) runs beside the discriminator forward on the real batch below; scaling by the loss
                 # coefficient afterwards is the same linear map on every rank
                 pending_g = self.dist.all_reduce_async(flat_g)
-            real_logits = D(rb).view(-1) if real_sum is None else None
+            if lane is not None:
+                lane.join()
+            elif real_sum is None:
+                real_logits = D(rb).view(-1)
             ops.logit_sums(gen_logits.view(-1), real_logits, sums, accumulate=True)
         if real_sum is not None:
             sums[1:2].copy_(real_sum)

@@ -583,6 +583,32 @@ def test_graph_replayed_step_equals_eager_step(stage, fade):
         assert np.array_equal(a, b)
 
 
+@pytest.mark.parametrize("stage,fade,use_graph", [(0, False, False), (1, True, False), (1, True, True)])
+def test_real_pass_on_second_stream_changes_nothing(stage, fade, use_graph):
+    """WGAN.overlap_passes: every discriminator pass over the real batch on the second stream (own gradient
+    buffer, own scratch lane) beside the pass over the generated batch.  Same kernels on the same data: metrics
+    and weights after 4 steps must equal the one-stream step bit for bit, eagerly and as a replayed graph."""
+    runs = []
+    for overlap in (False, True):
+        d, g, comp, _ = build(stage + 1)
+        gan = comp[stage][1 if fade else 0]
+        gan.seed(77)
+        gan.use_graph = use_graph
+        gan.overlap_passes = overlap
+        gan.set_train_steps(4)
+        metrics = []
+        for k in range(4):
+            real, _ = R.synthetic_inputs(stage, 8, seed=90 + k)
+            out = gan.train_step(real)
+            metrics.append({key: float(v) for key, v in out.items()})
+        weights = [v.numpy() for model in (gan.discriminator, gan.generator) for v in model.trainable_variables]
+        runs.append((metrics, weights))
+    (m_a, w_a), (m_b, w_b) = runs
+    assert m_a == m_b
+    for a, b in zip(w_a, w_b):
+        assert np.array_equal(a, b)
+
+
 def test_graph_survives_scratch_reallocation():
     """A captured graph carries the raw addresses of the library's scratch buffers.  Shape A is stepped twice
     (eager, then captured), a larger shape B follows and the workspace is grown beyond anything seen so far
