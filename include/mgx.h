@@ -151,6 +151,44 @@ int mgx_gblock_wgrad_f32(const float* act, const float* delta, const mgx_gblock_
                          int64_t workspace_bytes, int64_t npos, void* stream);
 
 /* ------------------------------------------------------------------------------------------
+ * Head of the stage-0 generator (define_generator, models.py:412-444): from the latent tensor z
+ * (nimg, 1, 100, 2) through featured = Conv2D(128, (1,2), strides (1,2)) (models.py:416) and, per branch
+ * b = 0..3, Conv2DTranspose(4,(2,1)) -> Dense(8) -> Conv2DTranspose(16,(2,1)) -> Dense(32)
+ * (models.py:418-421, 425-428, 432-435, 439-442) to the four tensors y[b] (nimg, 4, 50, 32) that the
+ * Conv2DTranspose(64, (1,15)) layers read: seventeen layers without an activation in one launch.
+ * Weights are the Keras-layout variables of the layers.
+ * ------------------------------------------------------------------------------------------ */
+typedef struct {
+    const float *k0, *b0;            /* Conv2D(128,(1,2),s(1,2)): kernel (1,2,2,128), bias (128)   */
+    const float *k1[4], *b1[4];      /* Conv2DTranspose(4,(2,1)): kernel (2,1,4,128), bias (4)      */
+    const float *d1[4], *c1[4];      /* Dense(8): kernel (4,8), bias (8)                            */
+    const float *k2[4], *b2[4];      /* Conv2DTranspose(16,(2,1)): kernel (2,1,16,8), bias (16)     */
+    const float *d2[4], *c2[4];      /* Dense(32): kernel (16,32), bias (32)                        */
+} mgx_ghead_weights;
+
+typedef struct {
+    float *k0, *b0;
+    float *k1[4], *b1[4];
+    float *d1[4], *c1[4];
+    float *k2[4], *b2[4];
+    float *d2[4], *c2[4];
+} mgx_ghead_grads;
+
+typedef struct {
+    float* y[4];                     /* per branch: (nimg, 4, 50, 32)                               */
+} mgx_ghead_tensors;
+
+int mgx_ghead_fwd_f32(const mgx_ghead_weights* w, const float* z, int64_t nimg, const mgx_ghead_tensors* out,
+                      void* stream);
+/* The head's part of tape.gradient (models.py:144-146): `dout->y[b]` holds d(loss)/d(y[b]) (read only); the
+ * weight and bias gradients of all 34 tensors are ADDED into `g` (per-wave partial sums in `workspace`,
+ * mgx_ghead_bwd_workspace(nimg) bytes, added in a fixed order: bitwise reproducible); g = NULL skips them.
+ * dz (nimg, 1, 100, 2), if not NULL, receives d(loss)/dz.  The intermediate tensors are re-computed from z. */
+int64_t mgx_ghead_bwd_workspace(int64_t nimg);
+int mgx_ghead_bwd_f32(const mgx_ghead_weights* w, const float* z, int64_t nimg, const mgx_ghead_tensors* dout,
+                      const mgx_ghead_grads* g, float* dz, void* workspace, int64_t workspace_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------------------
  * Non-contraction layers (HBM-bound, coalesced, wavefront reductions)
  * ------------------------------------------------------------------------------------------ */
 

@@ -46,6 +46,19 @@ class GBlockWeights(C.Structure):
                 ("w3", C.c_void_p), ("e3", C.c_void_p), ("w4", C.c_void_p), ("e4", C.c_void_p)]
 
 
+class GHeadWeights(C.Structure):
+    """mgx_ghead_weights / mgx_ghead_grads of include/mgx.h (device pointers to the variables, or to their
+    gradients, of the stage-0 generator's head)."""
+    _fields_ = [("k0", C.c_void_p), ("b0", C.c_void_p),
+                ("k1", C.c_void_p * 4), ("b1", C.c_void_p * 4), ("d1", C.c_void_p * 4), ("c1", C.c_void_p * 4),
+                ("k2", C.c_void_p * 4), ("b2", C.c_void_p * 4), ("d2", C.c_void_p * 4), ("c2", C.c_void_p * 4)]
+
+
+class GHeadTensors(C.Structure):
+    """mgx_ghead_tensors: the four per-branch tensors (nimg, 4, 50, 32)."""
+    _fields_ = [("y", C.c_void_p * 4)]
+
+
 _P = C.c_void_p
 _I64 = C.c_int64
 _I = C.c_int
@@ -59,6 +72,10 @@ PROTOTYPES = {
     "mgx_conv_wgrad_workspace": (_I64, [_DESC]),
     "mgx_conv_wgrad_f32": (_I, [_DESC, _P, _P, _P, _P, _P, _P, _I64, _P]),
     "mgx_conv_route": (_I, [_DESC, _I]),
+    "mgx_ghead_fwd_f32": (_I, [C.POINTER(GHeadWeights), _P, _I64, C.POINTER(GHeadTensors), _P]),
+    "mgx_ghead_bwd_workspace": (_I64, [_I64]),
+    "mgx_ghead_bwd_f32": (_I, [C.POINTER(GHeadWeights), _P, _I64, C.POINTER(GHeadTensors), C.POINTER(GHeadWeights), _P, _P,
+                               _I64, _P]),
     "mgx_gblock_pack_floats": (_I64, []),
     "mgx_gblock_side_floats_n": (_I64, [_I64]),
     "mgx_gblock_side_floats": (_I64, [_I64, _I, _I]),

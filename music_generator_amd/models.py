@@ -395,6 +395,88 @@ def add_generator_block(old_model):
     return [model1, model2]
 
 
+def _register_head_group(ly0, featured, branches, summed):
+    """Describe the sub-graph latent -> Add of define_generator to the executor: its first seventeen layers
+    (Conv2D(128,(1,2)) and, per branch, ConvT(4) -> Dense(8) -> ConvT(16) -> Dense(32)) run as one launch
+    (mgx_ghead_fwd_f32) and their gradients as two (mgx_ghead_bwd_f32); the ConvT(64,(1,15)), Dense(128) and Add
+    that follow keep their own kernels."""
+    feat_node = featured.node
+    chains = []
+    for bt in branches:
+        chain, u = [], bt
+        for _ in range(6):                  # Dense(128) <- ConvT(64) <- Dense(32) <- ConvT(16) <- Dense(8) <- ConvT(4)
+            chain.append(u.node)
+            u = u.node.inputs[0]
+        if u is not featured:
+            return
+        chains.append(chain[::-1])
+    add_node = summed.node
+    nodes = [feat_node] + [n for ch in chains for n in ch] + [add_node]
+    fields = [(feat_node.layer, "k0", "b0", None)]
+    for k, ch in enumerate(chains):
+        for name_k, name_b, node in (("k1", "b1", ch[0]), ("d1", "c1", ch[1]), ("k2", "b2", ch[2]), ("d2", "c2", ch[3])):
+            fields.append((node.layer, name_k, name_b, k))
+    expect = {"k0": (1, 2, 2, 128), "k1": (2, 1, 4, 128), "d1": (4, 8), "k2": (2, 1, 16, 8), "d2": (16, 32)}
+    for layer, name_k, _, _ in fields:
+        if tuple(layer.kernel.shape) != expect[name_k]:
+            return                          # not the reference's head: leave it to the layer kernels
+    tails = [(ch[4].layer, ch[5].layer) for ch in chains]          # ConvT(64,(1,15)), Dense(128)
+    add_layer = add_node.layer
+    state = {}
+
+    def pointers(of):
+        w = _cabi.GHeadWeights()
+        for layer, name_k, name_b, k in fields:
+            pk, pb = of(layer.kernel).data_ptr(), of(layer.bias).data_ptr()
+            if k is None:
+                setattr(w, name_k, pk)
+                setattr(w, name_b, pb)
+            else:
+                getattr(w, name_k)[k] = pk
+                getattr(w, name_b)[k] = pb
+        return w
+
+    def weights():
+        if "w" not in state:
+            state["w"] = pointers(lambda v: v.value())
+        return state["w"]
+
+    def forward(z, save):
+        n = z.shape[0]
+        ys = [K.empty((n, 4, 50, 32)) for _ in range(4)]
+        ops.ghead_fwd(weights(), z, ys)
+        outs, saved = [], []
+        for (convt, dense), y in zip(tails, ys):
+            t, s1 = convt.forward([y], save)
+            t, s2 = dense.forward([t], save)
+            outs.append(t)
+            saved.append((s1, s2))
+        out, s_add = add_layer.forward(outs, save)
+        return out, ((z, saved, s_add) if save else None)
+
+    def backward(saved_all, dy, need_weight_grads):
+        z, saved, s_add = saved_all
+        dbr = add_layer.backward(s_add, dy, [True] * 4, [None] * 4, need_weight_grads)
+        dys = []
+        for (convt, dense), (s1, s2), r in zip(tails, saved, dbr):
+            g = dense.backward(s2, r[0], [True], [None], need_weight_grads)[0][0]
+            dys.append(convt.backward(s1, g, [True], [None], need_weight_grads)[0][0])
+        grads = None
+        if need_weight_grads:
+            for layer, _, _, _ in fields:
+                if layer.kernel.grad is None or layer.bias.grad is None:
+                    raise RuntimeError("gradient buffers of %s are not bound" % layer.name)
+            grads = pointers(lambda v: v.grad)
+        dz = K.empty(z.shape)
+        ops.ghead_bwd(weights(), z, dys, grads, dz)
+        return dz
+
+    group = FusedGroup(ly0, summed, nodes, [], lambda z: forward(z, False)[0])
+    group.run_save = lambda z: forward(z, True)
+    group.backward = backward
+    summed.fused_group = group
+
+
 def define_generator(n_blocks):
     ly0 = Input(shape=(1, 100, 2))
     featured = Conv2D(128, (1, 2), strides=(1, 2), padding="valid", kernel_initializer="he_normal")(ly0)
@@ -405,7 +487,9 @@ def define_generator(n_blocks):
             g = Conv2DTranspose(filters, ksize, strides=ksize, padding="valid", kernel_initializer="he_normal")(g)
             g = Dense(units)(g)
         branches.append(g)
-    out = LayerNormalization(axis=[1, 2, 3])(_g_tail(Add()(branches)))
+    summed = Add()(branches)
+    _register_head_group(ly0, featured, branches, summed)
+    out = LayerNormalization(axis=[1, 2, 3])(_g_tail(summed))
     model = Model(ly0, out)
     model_list = [[model, model]]
     for i in range(1, n_blocks):

@@ -220,6 +220,58 @@ def _gblock_range(nimg, hl, wl, pos0, npos):
     return min(npos, total - pos0) if npos and npos > 0 else total - pos0
 
 
+GHEAD_FLOP_PER_SAMPLE = 2.0 * 50 * (128 * 4 + 4 * (8 * 128 + 16 * 4 + 64 * 8 + 128 * 16))
+
+
+def _ghead_tensors(ts, nimg):
+    from ._cabi import GHeadTensors
+    if len(ts) != 4:
+        raise MgxError("ghead: four branch tensors expected")
+    t = GHeadTensors()
+    for b, y in enumerate(ts):
+        if y.dtype != torch.float32 or not y.is_contiguous() or y.numel() != nimg * 4 * 50 * 32:
+            raise MgxError("ghead: branch tensor %d is not a contiguous float32 (n, 4, 50, 32)" % b)
+        t.y[b] = y.data_ptr()
+    return t
+
+
+def ghead_fwd(weights, z, ys):
+    """weights: _cabi.GHeadWeights; z (n,1,100,2) -> ys[b] (n,4,50,32), b = 0..3 (the head of the stage-0
+    generator in one launch)."""
+    nimg = z.shape[0]
+    if z.dtype != torch.float32 or not z.is_contiguous() or z.numel() != nimg * 200:
+        raise MgxError("ghead_fwd: z must be a contiguous float32 (n, 1, 100, 2)")
+    t = _ghead_tensors(ys, nimg)
+    e0 = PROFILER.start() if PROFILER is not None else None
+    check(_lib().mgx_ghead_fwd_f32(C.byref(weights), _p(z), nimg, C.byref(t), K.stream_ptr()), "mgx_ghead_fwd_f32")
+    if e0 is not None:
+        PROFILER.stop("ghead_fwd_kernel", GHEAD_FLOP_PER_SAMPLE * nimg, e0, 4.0 * nimg * (200 + 4 * 6400))
+
+
+def ghead_bwd(weights, z, dys, grads=None, dz=None):
+    """Given dys[b] = d(loss)/d(ys[b]): adds the weight / bias gradients of the head's 34 tensors into `grads`
+    (_cabi.GHeadWeights of gradient pointers; None: skipped) and writes d(loss)/dz into `dz` (None: skipped)."""
+    nimg = z.shape[0]
+    if z.dtype != torch.float32 or not z.is_contiguous() or z.numel() != nimg * 200:
+        raise MgxError("ghead_bwd: z must be a contiguous float32 (n, 1, 100, 2)")
+    if grads is None and dz is None:
+        raise MgxError("ghead_bwd: nothing to compute")
+    if dz is not None and (dz.dtype != torch.float32 or not dz.is_contiguous() or dz.numel() != z.numel()):
+        raise MgxError("ghead_bwd: dz must match z")
+    t = _ghead_tensors(dys, nimg)
+    nbytes, ws = 0, None
+    if grads is not None:
+        nbytes = int(_lib().mgx_ghead_bwd_workspace(nimg))
+        if nbytes <= 0:
+            raise MgxError("ghead_bwd: bad batch size")
+        ws = K.workspace(nbytes)
+    e0 = PROFILER.start() if PROFILER is not None else None
+    check(_lib().mgx_ghead_bwd_f32(C.byref(weights), _p(z), nimg, C.byref(t), C.byref(grads) if grads is not None else None,
+                                   _p(dz), ws.data_ptr() if ws is not None else None, nbytes, K.stream_ptr()), "mgx_ghead_bwd_f32")
+    if e0 is not None:
+        PROFILER.stop("ghead_bwd_kernel", 3.0 * GHEAD_FLOP_PER_SAMPLE * nimg, e0, 4.0 * nimg * (200 + 4 * 6400))
+
+
 def gblock_fwd(weights, pack, x, y, nimg, hl, wl, act=None, pos0=0, npos=0):
     """weights: _cabi.GBlockWeights; x (nimg,hl,wl,2) -> y (nimg,2hl,2wl,2) for the low-resolution
     positions [pos0, pos0+npos) (default: all).  `act` (optional) receives the intermediate tensors

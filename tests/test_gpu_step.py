@@ -347,14 +347,17 @@ def test_bench_workload_micro_batched_equals_whole_batch():
         assert rel_l2(g1[k], v) < tol, "%s: %.3e" % (k, rel_l2(g1[k], v))
 
 
-@pytest.mark.parametrize("stage,fade,batch,budget", [(1, False, 1, None), (1, True, 4, None), (2, True, 3, None),
+@pytest.mark.parametrize("stage,fade,batch,budget", [(0, False, 1, None), (0, False, 5, None), (0, False, 37, None),
+                                                     (1, False, 1, None), (1, True, 4, None), (2, True, 3, None),
                                                      (2, True, 3, 48 << 20), (1, False, 1, 1 << 20)])
 def test_fused_generator_backward_matches_layerwise(stage, fade, batch, budget):
     """The fused grow-block kernels (saving forward, register-chained data gradient, tile-major
     weight gradients) against the layer-by-layer taped path on the same device: output abs 2e-5 x max|y|,
     every gradient tensor rel-L2 2e-5 (float32 summation order is the only difference).  Batch
     1 and 3 leave the last 32-position tile partly empty; with a side-buffer budget the backward
-    re-computes the block's tensors over several position ranges."""
+    re-computes the block's tensors over several position ranges.  Stage 0 isolates the fused head of the base
+    generator (latent -> Dense(32) of the four branches in one launch, its 34 gradient tensors and d/dz in two);
+    batch 37 gives its backward waves several columns each and a ragged last pass."""
     from music_generator_amd.graph import FusedGroup, Model
     n_blocks = stage + 1
     d, g, comp, W = build(n_blocks)
