@@ -214,6 +214,15 @@ int mgx_weighted_sum_bwd(const float* dy, const float* a, const float* b, const 
                          void* workspace, int64_t workspace_bytes, int64_t n, void* stream);
 int64_t mgx_reduce_workspace(void);
 
+/* Per-clip checksums of a chunk of generated audio x (nclips, elems) (the tensors generar_ejemplo receives from
+ * g_model, utils.py:80-81 / 103-104): out[clip] = (sum, sum of squares, absolute peak) in float64, one read of
+ * the chunk, parts added in a fixed order.  elems a multiple of 4, x 16-byte aligned; workspace of
+ * mgx_clip_checksum_workspace(nclips) bytes.  No counterpart in the reference, which writes the audio out: it
+ * lets a sampling run or a benchmark consume a chunk on the device. */
+int64_t mgx_clip_checksum_workspace(int64_t nclips);
+int mgx_clip_checksum(const float* x, int64_t nclips, int64_t elems, double* out, void* workspace,
+                      int64_t workspace_bytes, void* stream);
+
 /* LayerNormalization(axis=[1,2,3]) (models.py:400, 405, 451): per-sample mean / biased variance
  * over e = H*W*C elements, epsilon eps, gamma/beta of e elements.  stats receives (mean, rstd)
  * per sample (2*nimg floats).  Backward: dx (+)=..., dgamma += , dbeta += (sums over the batch). */

@@ -76,6 +76,8 @@ PROTOTYPES = {
     "mgx_ghead_bwd_workspace": (_I64, [_I64]),
     "mgx_ghead_bwd_f32": (_I, [C.POINTER(GHeadWeights), _P, _I64, C.POINTER(GHeadTensors), C.POINTER(GHeadWeights), _P, _P,
                                _I64, _P]),
+    "mgx_clip_checksum_workspace": (_I64, [_I64]),
+    "mgx_clip_checksum": (_I, [_P, _I64, _I64, _P, _P, _I64, _P]),
     "mgx_gblock_pack_floats": (_I64, []),
     "mgx_gblock_side_floats_n": (_I64, [_I64]),
     "mgx_gblock_side_floats": (_I64, [_I64, _I, _I]),

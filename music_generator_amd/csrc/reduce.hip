@@ -97,6 +97,27 @@ __global__ __launch_bounds__(kBlock) void ln_apply_kernel(const float* __restric
         dst[e - 1] = (src[e - 1] - mean) * rstd * gamma[e - 1] + beta[e - 1];
 }
 
+// The same for samples whose gamma / beta do not stay in the L2 between samples (1 M elements and more): one
+// thread per four element positions loads gamma and beta once and walks the batch, so the two parameter
+// tensors are fetched once per call instead of once per sample.
+__global__ __launch_bounds__(kBlock) void ln_apply_batch4_kernel(const float4* __restrict__ x,
+                                                                 const float4* __restrict__ gamma,
+                                                                 const float4* __restrict__ beta,
+                                                                 const float* __restrict__ stats,
+                                                                 float4* __restrict__ y, long nimg, long e4) {
+    for (long i = (long)blockIdx.x * kBlock + threadIdx.x; i < e4; i += (long)gridDim.x * kBlock) {
+        const float4 g = gamma[i], b = beta[i];
+#pragma unroll 4
+        for (long n = 0; n < nimg; ++n) {
+            const float mean = stats[n * 2], rstd = stats[n * 2 + 1];
+            const f32x4 v = __builtin_nontemporal_load((const f32x4*)(x + n * e4 + i));
+            const f32x4 r = {(v[0] - mean) * rstd * g.x + b.x, (v[1] - mean) * rstd * g.y + b.y,
+                             (v[2] - mean) * rstd * g.z + b.z, (v[3] - mean) * rstd * g.w + b.w};
+            __builtin_nontemporal_store(r, (f32x4*)(y + n * e4 + i));
+        }
+    }
+}
+
 // ---------------- LayerNormalization backward ----------------
 // per-sample s1 = sum(dy*gamma), s2 = sum(dy*gamma*xhat)
 __global__ __launch_bounds__(kBlock) void ln_bwd_partial_kernel(const float* __restrict__ dy, const float* __restrict__ x,
@@ -532,7 +553,113 @@ __global__ __launch_bounds__(kBlock) void wgan_loss_kernel(const float* __restri
     }
 }
 
+// ---- per-clip checksums of a chunk of generated audio (sampling runs, utils.py:80-81 / 103-104) ----
+// One read of the chunk: block (part, clip) reduces a contiguous share of the clip to (sum, sum of squares,
+// peak) with float64 accumulators; a second kernel adds the parts of a clip in order.
+constexpr int kChecksumParts = 512;
+
+__global__ __launch_bounds__(256) void clip_checksum_partial_kernel(const f32x4* __restrict__ x, long quads_per_clip,
+                                                                    double* __restrict__ partial) {
+    __shared__ double red[3][4];
+    const long clip = blockIdx.y;
+    const long per = (quads_per_clip + gridDim.x - 1) / gridDim.x;
+    const long q0 = (long)blockIdx.x * per, q1 = q0 + per < quads_per_clip ? q0 + per : quads_per_clip;
+    const f32x4* src = x + clip * quads_per_clip;
+    double s = 0.0, ss = 0.0;
+    float pk = 0.f;
+    for (long q = q0 + threadIdx.x; q < q1; q += 256) {
+        const f32x4 v = __builtin_nontemporal_load(src + q);
+        const float t = (v[0] + v[1]) + (v[2] + v[3]);
+        const float t2 = (v[0] * v[0] + v[1] * v[1]) + (v[2] * v[2] + v[3] * v[3]);
+        s += (double)t;
+        ss += (double)t2;
+        pk = fmaxf(fmaxf(pk, fmaxf(fabsf(v[0]), fabsf(v[1]))), fmaxf(fabsf(v[2]), fabsf(v[3])));
+    }
+    double pd = (double)pk;
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        s += __shfl_down(s, off, 64);
+        ss += __shfl_down(ss, off, 64);
+        pd = fmax(pd, __shfl_down(pd, off, 64));
+    }
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    if (lane == 0) {
+        red[0][wv] = s;
+        red[1][wv] = ss;
+        red[2][wv] = pd;
+    }
+    __syncthreads();
+    if (threadIdx.x == 0) {
+        double* dst = partial + (clip * gridDim.x + blockIdx.x) * 3;
+        dst[0] = (red[0][0] + red[0][1]) + (red[0][2] + red[0][3]);
+        dst[1] = (red[1][0] + red[1][1]) + (red[1][2] + red[1][3]);
+        dst[2] = fmax(fmax(red[2][0], red[2][1]), fmax(red[2][2], red[2][3]));
+    }
+}
+
+__global__ __launch_bounds__(64) void clip_checksum_finish_kernel(const double* __restrict__ partial, int parts,
+                                                                  double* __restrict__ out) {
+    const long clip = blockIdx.x;
+    const int lane = threadIdx.x;
+    double s = 0.0, ss = 0.0, pk = 0.0;
+    for (int p = lane; p < parts; p += 64) {
+        const double* src = partial + (clip * parts + p) * 3;
+        s += src[0];
+        ss += src[1];
+        pk = fmax(pk, src[2]);
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+        s += __shfl_down(s, off, 64);
+        ss += __shfl_down(ss, off, 64);
+        pk = fmax(pk, __shfl_down(pk, off, 64));
+    }
+    if (lane == 0) {
+        out[clip * 3 + 0] = s;
+        out[clip * 3 + 1] = ss;
+        out[clip * 3 + 2] = pk;
+    }
+}
+
 }  // namespace
+
+extern "C" int64_t mgx_clip_checksum_workspace(int64_t nclips) {
+    return nclips > 0 ? nclips * kChecksumParts * 3 * (int64_t)sizeof(double) : -1;
+}
+
+extern "C" int mgx_clip_checksum(const float* x, int64_t nclips, int64_t elems, double* out, void* workspace,
+                                 int64_t workspace_bytes, void* stream) {
+    if (!x || !out || !workspace || nclips <= 0 || nclips > 65535 || elems <= 0 || (elems & 3)) return MGX_ERR_ARG;
+    if (((uintptr_t)x & 15) != 0) return MGX_ERR_ARG;
+    if (workspace_bytes < mgx_clip_checksum_workspace(nclips)) return MGX_ERR_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    const long quads = elems / 4;
+    const int parts = (int)(quads < kChecksumParts ? quads : kChecksumParts);
+    hipLaunchKernelGGL(clip_checksum_partial_kernel, dim3(parts, (unsigned)nclips), dim3(256), 0, st, (const f32x4*)x, quads,
+                       (double*)workspace);
+    hipLaunchKernelGGL(clip_checksum_finish_kernel, dim3((unsigned)nclips), dim3(64), 0, st, (const double*)workspace, parts,
+                       out);
+    return mgx_launch_status();
+}
+
+// second pass of the forward: per-sample grid, or the batch walk when gamma / beta are larger than an L2
+static void launch_ln_apply(const float* x, const float* gamma, const float* beta, const float* stats, float* y,
+                            int64_t nimg, int64_t e, hipStream_t st) {
+    if ((e & 3) == 0 && e >= (1L << 20) && nimg > 1) {
+        const long e4 = e / 4;
+        long g4 = (e4 + kBlock - 1) / kBlock;
+        if (g4 > 8192) g4 = 8192;
+        hipLaunchKernelGGL(ln_apply_batch4_kernel, dim3((unsigned)g4), dim3(kBlock), 0, st, (const float4*)x,
+                           (const float4*)gamma, (const float4*)beta, stats, (float4*)y, (long)nimg, e4);
+        return;
+    }
+    long gx = (e / 2 + kBlock - 1) / kBlock;
+    const long cap = 4096 / nimg > 0 ? 4096 / nimg : 1;
+    if (gx > cap) gx = cap;
+    if (gx < 1) gx = 1;
+    hipLaunchKernelGGL(ln_apply_kernel, dim3((unsigned)gx, (unsigned)nimg), dim3(kBlock), 0, st, x, gamma, beta, stats, y,
+                       (long)e);
+}
 
 extern "C" int64_t mgx_layernorm_workspace(int64_t nimg, int64_t e) {
     if (nimg <= 0 || e <= 0) return -1;
@@ -550,12 +677,7 @@ extern "C" int mgx_layernorm_fwd(const float* x, const float* gamma, const float
     double* part = (double*)workspace;
     hipLaunchKernelGGL(ln_partial_kernel, dim3((unsigned)bps, (unsigned)nimg), dim3(kBlock), 0, st, x, part, (long)e, bps);
     hipLaunchKernelGGL(ln_stats_kernel, dim3((unsigned)nimg), dim3(64), 0, st, part, stats, (long)e, bps, eps);
-    long gx = (e / 2 + kBlock - 1) / kBlock;
-    const long cap = 4096 / nimg > 0 ? 4096 / nimg : 1;
-    if (gx > cap) gx = cap;
-    if (gx < 1) gx = 1;
-    hipLaunchKernelGGL(ln_apply_kernel, dim3((unsigned)gx, (unsigned)nimg), dim3(kBlock), 0, st, x, gamma, beta, stats, y,
-                       (long)e);
+    launch_ln_apply(x, gamma, beta, stats, y, nimg, e, st);
     return mgx_launch_status();
 }
 
@@ -603,12 +725,7 @@ extern "C" int mgx_layernorm_fwd_static(const float* x, const float* gamma, cons
     // every pair the second kernel reads is written by the first one of the same call: nothing to clear
     hipLaunchKernelGGL(ln_partial_kernel, dim3((unsigned)bps, (unsigned)nimg), dim3(kBlock), 0, st, x, part, (long)e, bps);
     hipLaunchKernelGGL(ln_stats_kernel, dim3((unsigned)nimg), dim3(64), 0, st, part, stats, (long)e, bps, eps);
-    long gx = (e / 2 + kBlock - 1) / kBlock;
-    const long cap = 4096 / nimg > 0 ? 4096 / nimg : 1;
-    if (gx > cap) gx = cap;
-    if (gx < 1) gx = 1;
-    hipLaunchKernelGGL(ln_apply_kernel, dim3((unsigned)gx, (unsigned)nimg), dim3(kBlock), 0, st, x, gamma, beta, stats, y,
-                       (long)e);
+    launch_ln_apply(x, gamma, beta, stats, y, nimg, e, st);
     return mgx_launch_status();
 }
 

@@ -16,6 +16,7 @@ import numpy as np
 import torch
 
 from . import backend as K
+from . import ops
 
 
 def draw_latents(n: int, latent_dim: Sequence[int] = (1, 100, 2), seed: Optional[int] = None, device=None):
@@ -58,7 +59,7 @@ def generate_clips(g_model, n: int, chunk: int = 8, sink: Optional[Callable] = N
 
 class ChecksumSink:
     """Reduces every chunk on the device to per-clip sum, sum of squares and absolute peak (float64
-    accumulators, no host synchronisation until `result()`)."""
+    accumulators, one pass over the chunk, no host synchronisation until `result()`)."""
 
     def __init__(self):
         self._rows: List[torch.Tensor] = []
@@ -66,18 +67,10 @@ class ChecksumSink:
 
     def __call__(self, first: int, audio: torch.Tensor):
         m = audio.shape[0]
-        size = audio.numel() // max(m, 1)
-        # three single-pass reductions, accumulated in float64 without a float64 copy of the chunk.  A clip is
-        # reduced in `parts` pieces first: a handful of rows of 25 M elements would leave most of the GPU idle.
-        parts = 1
-        while parts < 4096 and size % (2 * parts) == 0:
-            parts *= 2
-        a = audio.reshape(m * parts, size // parts)
-        norm = torch.linalg.vector_norm(a, ord=2, dim=1, dtype=torch.float64).view(m, parts)
-        peak = torch.linalg.vector_norm(a, ord=float("inf"), dim=1).view(m, parts)
-        total = a.sum(1, dtype=torch.float64).view(m, parts)
-        self._rows.append(torch.stack([total.sum(1), (norm * norm).sum(1), peak.amax(1).double()], dim=1))
-        self.clips += audio.shape[0]
+        row = torch.empty((m, 3), dtype=torch.float64, device=audio.device)
+        ops.clip_checksum(audio.contiguous(), row)     # one read of the chunk (mgx_clip_checksum)
+        self._rows.append(row)
+        self.clips += m
 
     def result(self) -> np.ndarray:
         """(clips, 3) float64: sum, sum of squares, peak of every clip in generation order."""

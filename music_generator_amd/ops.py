@@ -220,6 +220,23 @@ def _gblock_range(nimg, hl, wl, pos0, npos):
     return min(npos, total - pos0) if npos and npos > 0 else total - pos0
 
 
+def clip_checksum(audio, out):
+    """audio (m, ...) contiguous float32 -> out (m, 3) float64: per-clip sum, sum of squares, absolute peak."""
+    m = audio.shape[0]
+    elems = audio.numel() // max(m, 1)
+    if audio.dtype != torch.float32 or not audio.is_contiguous() or m < 1 or elems % 4:
+        raise MgxError("clip_checksum: contiguous float32 clips with a multiple of 4 elements expected")
+    if out.dtype != torch.float64 or not out.is_contiguous() or tuple(out.shape) != (m, 3):
+        raise MgxError("clip_checksum: out must be a contiguous float64 (m, 3)")
+    nbytes = int(_lib().mgx_clip_checksum_workspace(m))
+    ws = K.workspace(nbytes)
+    e0 = PROFILER.start() if PROFILER is not None else None
+    check(_lib().mgx_clip_checksum(_p(audio), m, elems, out.data_ptr(), ws.data_ptr(), nbytes, K.stream_ptr()),
+          "mgx_clip_checksum")
+    if e0 is not None:
+        PROFILER.stop("clip_checksum", 0.0, e0, 4.0 * audio.numel())
+
+
 GHEAD_FLOP_PER_SAMPLE = 2.0 * 50 * (128 * 4 + 4 * (8 * 128 + 16 * 4 + 64 * 8 + 128 * 16))
 
 

@@ -164,6 +164,9 @@ def test_layer_normalization():
            lambda x, wt: R.layer_norm(x, wt["gamma"], wt["beta"]), (4, 750, 2), 5)
     _check(lambda t: L.LayerNormalization(axis=[1, 2, 3])(t),
            lambda x, wt: R.layer_norm(x, wt["gamma"], wt["beta"]), (16, 3000, 2), 2)
+    # 2^20 elements per sample: the second pass walks the batch per element position (gamma / beta read once)
+    _check(lambda t: L.LayerNormalization(axis=[1, 2, 3])(t),
+           lambda x, wt: R.layer_norm(x, wt["gamma"], wt["beta"]), (64, 8192, 2), 3)
 
 
 @pytest.mark.parametrize("batch", [1, 2, 4, 8, 12])
