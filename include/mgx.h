@@ -83,7 +83,8 @@ int mgx_conv_wgrad_f32(const mgx_conv_desc* d, const float* x, const float* dy, 
  * channels and no activation, then also with 128 output channels; the tile kernels otherwise;
  * MGX_WINOGRAD=0 in the environment turns it off), 4 = Dense-chain GEMM with the weight matrix in LDS
  * (1x1, 64 / 128 / 256 channels on both sides, no multiplier, activation or accumulation: the
- * stage-0 generator's Dense layers and their data-gradients).  `wgrad` = 0 asks about mgx_conv_gemm_f32
+ * stage-0 generator's Dense layers and their data-gradients), 5 = tap-parallel GEMM for the data-gradient of a
+ * Conv2DTranspose with kernel (1,T) = stride, 64 filters -> 32 channels (models.py:422).  `wgrad` = 0 asks about mgx_conv_gemm_f32
  * without an input multiplier, 2 about mgx_conv_gemm_f32 with one, 1 about mgx_conv_wgrad_f32.
  * d->act_alpha is taken into account.  No counterpart in the reference: it lets a caller label its
  * timings with the kernel that actually ran. */

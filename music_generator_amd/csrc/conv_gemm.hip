@@ -19,6 +19,8 @@ int mgx_wconv_launch(const mgx_conv_desc& d, const float* x, const float* xmul, 
 int mgx_tconv_launch(const mgx_conv_desc& d, const float* x, const float* xmul, const float* w, const float* bias,
                      float* y, float* dact, hipStream_t st);
 bool mgx_pgemm_applicable(const mgx_conv_desc& d, bool mul);   // pgemm.hip
+bool mgx_tapsum_applicable(const mgx_conv_desc& d, bool mul);
+int mgx_tapsum_launch(const mgx_conv_desc& d, const float* x, const float* w, float* y, hipStream_t st);
 int mgx_pgemm_launch(const mgx_conv_desc& d, const float* x, const float* w, const float* bias, float* y,
                      hipStream_t st);
 
@@ -426,6 +428,7 @@ extern "C" int mgx_conv_gemm_f32(const mgx_conv_desc* dp, const float* x, const 
     if (pointwise2_applicable(d, xmul)) return launch_pointwise2(d, x, w, bias, y, dact, st);
     if (pointwise_to2_applicable(d) && !dact) return launch_pointwise_to2(d, x, xmul, w, bias, y, st);
     if (mgx_pgemm_applicable(d, xmul != nullptr)) return mgx_pgemm_launch(d, x, w, bias, y, st);
+    if (mgx_tapsum_applicable(d, xmul != nullptr) && !dact) return mgx_tapsum_launch(d, x, w, y, st);
     const int ntiles = (d.ngemm + 31) / 32;
     if (ntiles == 1) return launch_pn<4, 1>(d, x, xmul, w, bias, y, dact, st);
     if (ntiles == 2) return launch_pn<2, 2>(d, x, xmul, w, bias, y, dact, st);

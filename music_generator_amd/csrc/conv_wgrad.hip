@@ -96,6 +96,12 @@ WgradPlan make_plan(const mgx_conv_desc& d) {
     return p;
 }
 
+// one tap, stride 1, no padding, no depth-to-space: rows of X and dY are plain offsets
+bool dense_layer(const mgx_conv_desc& d) {
+    return d.kh == 1 && d.kw == 1 && d.sh == 1 && d.sw == 1 && d.pt == 0 && d.pl == 0 && d.dkh == 1 && d.dkw == 1 &&
+           d.hin == d.hout && d.win == d.wout && d.cout == d.ngemm;
+}
+
 template <int T, int KT, int NT>
 __global__ __launch_bounds__(256) void wgrad_kernel(mgx_conv_desc d, const float* __restrict__ x,
                                                     const float* __restrict__ dy,
@@ -224,6 +230,109 @@ __global__ __launch_bounds__(256) void wgrad_kernel(mgx_conv_desc d, const float
                 for (int reg = 0; reg < 16; ++reg) dst[reg * 64] = acc[t][kt][nt][reg];
             }
     if (bpartial && tg == 0 && kg == 0) {
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+            if ((nt0 + nt) < ntot) bpartial[(split * ntot + (nt0 + nt)) * 64 + lane] = bsum[nt];
+    }
+}
+
+// The same for a Dense layer (one tap, stride 1, no padding, no scatter): row r of X and of dY are plain
+// offsets r * cin and r * ngemm, so a step costs its loads and MFMAs only, and four steps of operands are in
+// flight ahead of the MFMAs (per-lane dword loads straight from global memory: one step ahead leaves most of
+// their latency exposed when a wave has ~50 steps in all).  Same slabs, same order of summation per wave.
+template <int KT, int NT>
+__global__ __launch_bounds__(256) void dense_wgrad_kernel(mgx_conv_desc d, const float* __restrict__ x,
+                                                          const float* __restrict__ dy,
+                                                          const float* __restrict__ dymul, float* __restrict__ partial,
+                                                          float* __restrict__ bpartial, int k_groups, int ktot, int ntot,
+                                                          long rows_per_split, long tiles_total) {
+    const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const long split = (long)blockIdx.x * 4 + wv;
+    const int kg = blockIdx.y % k_groups, ng = blockIdx.y / k_groups;
+    const int kt0 = kg * KT, nt0 = ng * NT;
+    const long R = (long)d.nimg * d.hout * d.wout;
+    const long rbeg = split * rows_per_split;
+    long rend = rbeg + rows_per_split;
+    if (rend > R) rend = R;
+
+    f32x16 acc[KT][NT];
+#pragma unroll
+    for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[kt][nt][i] = 0.f;
+    float bsum[NT];
+    int ncol[NT], kcol[KT];
+    bool nok[NT], kok[KT];
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) {
+        bsum[nt] = 0.f;
+        ncol[nt] = (nt0 + nt) * 32 + r;
+        nok[nt] = (nt0 + nt) < ntot && ncol[nt] < d.ngemm;
+    }
+#pragma unroll
+    for (int kt = 0; kt < KT; ++kt) {
+        kcol[kt] = (kt0 + kt) * 32 + r;
+        kok[kt] = (kt0 + kt) < ktot && kcol[kt] < d.cin;
+    }
+    if (rbeg < rend) {
+        constexpr int DEPTH = 4;
+        long row = rbeg + h;
+        const float* xp = x + row * d.cin;
+        const float* yp = dy + row * d.ngemm;
+        const float* mp = dymul ? dymul + row * d.ngemm : nullptr;
+        const long xs = 2L * d.cin, ys = 2L * d.ngemm;
+        float bv[DEPTH][NT], av[DEPTH][KT];
+        auto load = [&](float (&b)[NT], float (&a)[KT]) {
+            const bool rv = row < rend;
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) {
+                float v = 0.f;
+                if (rv && nok[nt]) {
+                    v = yp[ncol[nt]];
+                    if (mp) v *= mp[ncol[nt]];
+                }
+                b[nt] = v;
+            }
+#pragma unroll
+            for (int kt = 0; kt < KT; ++kt) a[kt] = (rv && kok[kt]) ? xp[kcol[kt]] : 0.f;
+            row += 2;
+            xp += xs;
+            yp += ys;
+            if (mp) mp += ys;
+        };
+        auto mma = [&](const float (&b)[NT], const float (&a)[KT]) {
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt) bsum[nt] += b[nt];
+#pragma unroll
+            for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+                for (int nt = 0; nt < NT; ++nt) acc[kt][nt] = mfma32(a[kt], b[nt], acc[kt][nt]);
+        };
+        const long steps = (rend - rbeg + 1) / 2;          // row pairs (the same for both lane halves)
+#pragma unroll
+        for (int q = 0; q < DEPTH - 1; ++q) load(bv[q], av[q]);       // rows past the end load zeros
+        for (long s0 = 0; s0 < steps; s0 += DEPTH) {
+#pragma unroll
+            for (int q = 0; q < DEPTH; ++q) {
+                load(bv[(q + DEPTH - 1) % DEPTH], av[(q + DEPTH - 1) % DEPTH]);
+                if (s0 + q < steps) mma(bv[q], av[q]);
+            }
+        }
+    }
+#pragma unroll
+    for (int kt = 0; kt < KT; ++kt)
+#pragma unroll
+        for (int nt = 0; nt < NT; ++nt) {
+            if ((kt0 + kt) >= ktot || (nt0 + nt) >= ntot) continue;
+            const long tile = (long)(kt0 + kt) * ntot + (nt0 + nt);
+            float* dst = partial + ((split * tiles_total + tile) * 16) * 64 + lane;
+#pragma unroll
+            for (int reg = 0; reg < 16; ++reg) dst[reg * 64] = acc[kt][nt][reg];
+        }
+    if (bpartial && kg == 0) {
 #pragma unroll
         for (int nt = 0; nt < NT; ++nt)
             if ((nt0 + nt) < ntot) bpartial[(split * ntot + (nt0 + nt)) * 64 + lane] = bsum[nt];
@@ -442,6 +551,18 @@ extern "C" int mgx_conv_wgrad_f32(const mgx_conv_desc* dp, const float* x, const
 #define MGX_WG(TT, KK, NN) launch_wgrad<TT, KK, NN>(d, p, x, dy, dymul, partial, bpartial, st)
     if (p.tiled) {
         if (mgx_twgrad_launch(d, x, dy, dymul, partial, bpartial, st) != MGX_OK) return MGX_ERR_LAUNCH;
+    } else if (dense_layer(d)) {
+        dim3 grid((unsigned)(p.splits / 4), (unsigned)(p.k_groups * p.n_groups)), block(256);
+#define MGX_DW(KK, NN)                                                                                              \
+    hipLaunchKernelGGL((dense_wgrad_kernel<KK, NN>), grid, block, 0, st, d, x, dy, dymul, partial, bpartial, p.k_groups, \
+                       p.ktot, p.ntot, p.rows_per_split, p.tiles_total)
+        if (p.KT == 1 && p.NT == 1) MGX_DW(1, 1);
+        else if (p.KT == 1 && p.NT == 2) MGX_DW(1, 2);
+        else if (p.KT == 1 && p.NT == 4) MGX_DW(1, 4);
+        else if (p.KT == 2 && p.NT == 1) MGX_DW(2, 1);
+        else if (p.KT == 2 && p.NT == 2) MGX_DW(2, 2);
+        else MGX_DW(2, 4);
+#undef MGX_DW
     } else if (p.T == 9) MGX_WG(9, 1, 1);
     else if (p.T == 8) MGX_WG(8, 1, 1);
     else if (p.T == 4) MGX_WG(4, 1, 1);

@@ -118,7 +118,72 @@ int launch_kn(const mgx_conv_desc& d, const float* x, const float* w, const floa
     return mgx_launch_status();
 }
 
+// ------------------------------------------------------------------------------------------------------
+// Data-gradient of a Conv2DTranspose whose kernel (1, T) equals its stride, 64 filters -> 32 channels (the
+// (1,15) layers of the stage-0 generator, models.py:422): dX[row][c] = sum_t sum_f dY[row][t][f] W[t][f][c],
+// a GEMM with few rows (200 per sample) and K = 64 T.  One wave per tap: a workgroup of 16 waves takes 32
+// rows, wave t multiplies its tap's 64-deep slice, and the T partial tiles are added through LDS in tap order.
+// (With the rows on the workgroups alone a batch of 16 gives 25 workgroups walking K = 960 one after the
+// other: 146 us; this form: all taps at once.)
+// ------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(1024) void tapsum_kernel(const float* __restrict__ x, const float* __restrict__ w,
+                                                      float* __restrict__ y, long R, int T) {
+    __shared__ float red[16][16][64];
+    const int tid = threadIdx.x, lane = tid & 63, t = tid >> 6;
+    const int r = lane & 31, h = lane >> 5;
+    const long row0 = (long)blockIdx.x * 32;
+    if (t < T) {
+        long rows = R - row0;
+        rows = rows > 32 ? 32 : rows;
+        const __amdgpu_buffer_rsrc_t rx = __builtin_amdgcn_make_buffer_rsrc((void*)(x + row0 * T * 64), 0,
+                                                                            (unsigned)(rows * T * 64 * 4), 0x00020000);
+        const unsigned a_voff = (unsigned)(((r * T + t) * 64 + 4 * h) * 4);
+        f32x4 a[8];
+#pragma unroll
+        for (int s = 0; s < 8; ++s)
+            a[s] = __builtin_bit_cast(f32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, a_voff, s * 32, 0));
+        const float* wt = w + (long)t * 2048 + (4 * h) * 32 + r;
+        float b[8][4];
+#pragma unroll
+        for (int s = 0; s < 8; ++s)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) b[s][j] = wt[(8 * s + j) * 32];
+        f32x16 acc;
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[i] = 0.f;
+#pragma unroll
+        for (int s = 0; s < 8; ++s)
+#pragma unroll
+            for (int j = 0; j < 4; ++j) acc = mfma32(a[s][j], b[s][j], acc);
+#pragma unroll
+        for (int i = 0; i < 16; ++i) red[t][i][lane] = acc[i];
+    }
+    __syncthreads();
+    const int reg = tid >> 6;
+    float v = red[0][reg][lane];
+    for (int q = 1; q < T; ++q) v += red[q][reg][lane];
+    const long row = row0 + (reg & 3) + 8 * (reg >> 2) + 4 * h;
+    if (row < R) y[row * 32 + r] = v;
+}
+
 }  // namespace
+
+bool mgx_tapsum_applicable(const mgx_conv_desc& d, bool mul) {
+    if (mul || d.accumulate || d.act_alpha > 0.f || d.nbias != 0 || d.flip) return false;
+    if (d.kh != 1 || d.sh != 1 || d.kw < 2 || d.kw > 16 || d.sw != d.kw || d.dkh != 1 || d.dkw != 1) return false;
+    if (d.pt != 0 || d.pl != 0 || d.hin != d.hout || d.win != d.wout * d.kw) return false;
+    if (d.cin != 64 || d.ngemm != 32 || d.cout != 32) return false;
+    if (d.wsn != 1 || d.wsk != 32 || d.wtap != 2048) return false;
+    return (long)32 * d.kw * 64 * 4 < (1L << 31);
+}
+
+int mgx_tapsum_launch(const mgx_conv_desc& d, const float* x, const float* w, float* y, hipStream_t st) {
+    const long R = (long)d.nimg * d.hout * d.wout;
+    const long grid = (R + 31) / 32;
+    if (grid >= (1L << 31)) return MGX_ERR_ARG;
+    hipLaunchKernelGGL(tapsum_kernel, dim3((unsigned)grid), dim3(1024), 0, st, x, w, y, R, (int)d.kw);
+    return mgx_launch_status();
+}
 
 // 1x1 stride-1 contraction without input multiplier, activation, accumulation or scatter, K and N in
 // {64, 128, 256} with K*N*4 bytes of weights <= 128 KiB, dense [k][n] or [n][k] weights.

@@ -275,6 +275,7 @@ bool mgx_wconv_enabled();                                  // conv_gemm.hip
 bool mgx_wconv_applicable(const mgx_conv_desc& d, bool mul);   // wconv.hip
 bool mgx_wwgrad_applicable(const mgx_conv_desc& d);            // wwgrad.hip
 bool mgx_pgemm_applicable(const mgx_conv_desc& d, bool mul);   // pgemm.hip
+bool mgx_tapsum_applicable(const mgx_conv_desc& d, bool mul);
 
 extern "C" int mgx_conv_route(const mgx_conv_desc* d, int wgrad) {
     if (!d) return 0;
@@ -286,7 +287,8 @@ extern "C" int mgx_conv_route(const mgx_conv_desc* d, int wgrad) {
     if (mgx_tconv_applicable(*d)) return 1;
     if (mgx_pointwise_to2_applicable(*d)) return 2;
     if (mgx_pointwise2_applicable(*d) && wgrad == 0) return 2;
-    return mgx_pgemm_applicable(*d, wgrad == 2) ? 4 : 0;
+    if (mgx_pgemm_applicable(*d, wgrad == 2)) return 4;
+    return mgx_tapsum_applicable(*d, wgrad == 2) ? 5 : 0;
 }
 
 long mgx_twgrad_splits(const mgx_conv_desc& d) {

@@ -86,6 +86,8 @@ def _gemm_key(d: ConvDesc, mul: bool = False) -> str:
         return "wino3_kernel"
     if route == 4:
         return "pgemm_kernel<%d,%d,%s>" % (d.cin // 8, d.ngemm // 32, "true" if d.wsk == 1 else "false")
+    if route == 5:
+        return "tapsum_kernel"
     if route == 1:
         kh, kw = (1, 1) if d.sh == 2 else (d.kh, d.kw)      # the strided form runs as a 1x1 kernel over gathered windows
         return "tconv3_kernel<%d,%d,%s,%s>" % (kh, kw, "true" if d.wsk == 1 else "false",
