@@ -221,14 +221,16 @@ __device__ __forceinline__ u32x4 frag(const unsigned char* buf, int f, int lane)
 
 // fragments [f0, f0 + n) of the packed weights -> LDS at dst, one fragment per wave-instruction
 __device__ __forceinline__ void stage(const unsigned char* __restrict__ packb, int f0, int n, unsigned char* dst, int wv,
-                                      int lane) {
-    for (int f = wv; f < n; f += 4)
+                                      int lane, int nw = 4) {
+    for (int f = wv; f < n; f += nw)
         __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(packb + (long)(f0 + f) * 1024 + lane * 16),
                                          (__attribute__((address_space(3))) void*)(dst + f * 1024), 16, 0, 0);
 }
 
-template <bool SAVE>
-__global__ __launch_bounds__(256, 1) void gblock_fwd_bf16_kernel(const unsigned char* __restrict__ packb,
+// NW waves per workgroup share the staged weight fragments: 4 (one per SIMD), or 8 for the forward that keeps no tape
+// (two per SIMD: the conversions of one wave run beside the MFMAs of the other)
+template <bool SAVE, int NW>
+__global__ __launch_bounds__(64 * NW, 1) void gblock_fwd_bf16_kernel(const unsigned char* __restrict__ packb,
                                                                  const float* __restrict__ x, float* __restrict__ y,
                                                                  bf16_t* __restrict__ act, long pos0, long npix, int hl,
                                                                  int wl, long ntiles) {
@@ -244,7 +246,7 @@ __global__ __launch_bounds__(256, 1) void gblock_fwd_bf16_kernel(const unsigned 
     float* bias = (float*)(lds + 4 * 1024 + 2 * BUF_BYTES + 8 * TL_BYTES);
     {
         const float* gbias = (const float*)(packb + (long)NFB * 1024);
-        for (int i = threadIdx.x; i < NBIAS; i += 256) bias[i] = gbias[i];
+        for (int i = threadIdx.x; i < NBIAS; i += 64 * NW) bias[i] = gbias[i];
     }
 
     // phase q of a sub-row: fragments [phase_f0(q), + phase_n(q))
@@ -253,12 +255,12 @@ __global__ __launch_bounds__(256, 1) void gblock_fwd_bf16_kernel(const unsigned 
 
     long tile = blockIdx.x;
     if (tile >= ntiles) return;
-    stage(packb, FB_F, 4, fbuf, wv, lane);
-    stage(packb, phase_f0(0), phase_n(0), pbuf, wv, lane);
+    stage(packb, FB_F, 4, fbuf, wv, lane, NW);
+    stage(packb, phase_f0(0), phase_n(0), pbuf, wv, lane, NW);
     __syncthreads();
     int par = 0;                                             // buffer of the current phase
     for (; tile < ntiles; tile += gridDim.x) {
-        const long p = pos0 + tile * 128 + wv * 32 + r;     // side-buffer tiles are counted from pos0
+        const long p = pos0 + tile * (32 * NW) + wv * 32 + r;     // side-buffer tiles are counted from pos0
         const bool pvalid = p < npix;
         const long pc = pvalid ? p : 0;
         // positions past the end contribute activations of a zero input; their gradients are zero
@@ -266,7 +268,7 @@ __global__ __launch_bounds__(256, 1) void gblock_fwd_bf16_kernel(const unsigned 
         const long row = pc / wl;
         const int jcol = (int)(pc - row * wl);
         float* yrow0 = y ? y + ((row * 2) * (2L * wl) + 2L * jcol) * 2 : nullptr;
-        bf16_t* at = SAVE ? act + (tile * 4 + wv) * (GB_ROWS * 32L) : nullptr;
+        bf16_t* at = SAVE ? act + (tile * NW + wv) * (GB_ROWS * 32L) : nullptr;
         // B operand of the featured conv: element j = x[channel j & 1] for each of the 4 taps.  Only 8 of the
         // 16 contraction slots are needed, so the block input goes in as two bf16 parts, x = hi + lo (lane
         // half 0 carries hi, half 1 the remainder): the 2-channel input keeps 16 significant bits.
@@ -298,7 +300,7 @@ __global__ __launch_bounds__(256, 1) void gblock_fwd_bf16_kernel(const unsigned 
                 for (int ot = 0; ot < 4; ++ot) init_bias(S[b][ot], bias + BO_SUM + ot * 32, h, 127, 4);
 #pragma unroll 1
             for (int k = 0; k < 6; ++k) {
-                stage(packb, phase_f0(k + 1), phase_n(k + 1), pbuf + (par ^ 1) * BUF_BYTES, wv, lane);
+                stage(packb, phase_f0(k + 1), phase_n(k + 1), pbuf + (par ^ 1) * BUF_BYTES, wv, lane, NW);
                 const unsigned char* wb = pbuf + par * BUF_BYTES;
                 const float* bb = bias + BO_BR + k * BBR;
                 f32x16 o1;
@@ -338,6 +340,8 @@ __global__ __launch_bounds__(256, 1) void gblock_fwd_bf16_kernel(const unsigned 
                                     mfma_bf16_pinned(S[b][ot], frag(wb, FB_D2 + (ot * 2 + it) * 2 + ks, lane), o3b[it].k[ks]);
                                 else            // 380 -> 482 TFLOP/s pinned; the plain forward loses with it (831 -> 813)
                                     S[b][ot] = mfma_bf16(frag(wb, FB_D2 + (ot * 2 + it) * 2 + ks, lane), o3b[it].k[ks], S[b][ot]);
+                    // two waves per SIMD have 256 registers each: keep the two sub-columns from being interleaved
+                    if (NW == 8) __builtin_amdgcn_sched_barrier(0);
                 }
                 __syncthreads();                      // waits for this wave's DMA, then for every wave
                 par ^= 1;
@@ -363,8 +367,8 @@ __global__ __launch_bounds__(256, 1) void gblock_fwd_bf16_kernel(const unsigned 
 #pragma unroll 1
             for (int half = 0; half < 2; ++half) {
                 // next phase: the second tail half, then branch 0 of the next sub-row / tile
-                if (half == 0) stage(packb, phase_f0(7), phase_n(7), pbuf + (par ^ 1) * BUF_BYTES, wv, lane);
-                else if (A == 0 || more_tiles) stage(packb, phase_f0(0), phase_n(0), pbuf + (par ^ 1) * BUF_BYTES, wv, lane);
+                if (half == 0) stage(packb, phase_f0(7), phase_n(7), pbuf + (par ^ 1) * BUF_BYTES, wv, lane, NW);
+                else if (A == 0 || more_tiles) stage(packb, phase_f0(0), phase_n(0), pbuf + (par ^ 1) * BUF_BYTES, wv, lane, NW);
                 const unsigned char* wb = pbuf + par * BUF_BYTES;
 #pragma unroll 1
                 for (int cc = 0; cc < 4; ++cc) {
@@ -675,6 +679,17 @@ bool weights_set(const mgx_gblock_weights& w) {
 }
 }  // namespace
 
+// Waves per workgroup of the forward without a tape: 8 (two per SIMD, 256 registers each; measured 304 against
+// 262 clips/s of stage-6 inference with 4, whose single wave per SIMD waits on its own conversions between
+// MFMAs); MGX_GBLOCK_WAVES=4 in the environment selects the one-wave-per-SIMD form.
+static int fwd_waves() {
+    static const int nw = [] {
+        const char* e = getenv("MGX_GBLOCK_WAVES");
+        return (e && e[0] == '4') ? 4 : 8;
+    }();
+    return nw;
+}
+
 extern "C" int mgx_gblock_fwd_bf16(const mgx_gblock_weights* wp, void* packb, const float* x, float* y, void* act,
                                    int64_t nimg, int hl, int wl, int64_t pos0, int64_t npos, void* stream) {
     if (!wp || !packb || !x || (!y && !act) || nimg <= 0 || hl <= 0 || wl <= 0) return MGX_ERR_ARG;
@@ -689,17 +704,25 @@ extern "C" int mgx_gblock_fwd_bf16(const mgx_gblock_weights* wp, void* packb, co
         hipLaunchKernelGGL(gblock_pack_bf16_kernel, dim3((NFB * 512 + 255) / 256), dim3(256), 0, st, w, (unsigned char*)packb);
     const unsigned grid = (unsigned)(ntiles < 256 ? ntiles : 256);
     if (act) {
-        if (hipFuncSetAttribute((const void*)gblock_fwd_bf16_kernel<true>, hipFuncAttributeMaxDynamicSharedMemorySize,
+        if (hipFuncSetAttribute((const void*)gblock_fwd_bf16_kernel<true, 4>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 LDS_BYTES) != hipSuccess)
             return MGX_ERR_LAUNCH;
-        hipLaunchKernelGGL(gblock_fwd_bf16_kernel<true>, dim3(grid), dim3(256), LDS_BYTES, st, (const unsigned char*)packb, x,
-                           y, (bf16_t*)act, (long)pos0, end, hl, wl, ntiles);
+        hipLaunchKernelGGL((gblock_fwd_bf16_kernel<true, 4>), dim3(grid), dim3(256), LDS_BYTES, st,
+                           (const unsigned char*)packb, x, y, (bf16_t*)act, (long)pos0, end, hl, wl, ntiles);
+    } else if (fwd_waves() == 8) {
+        const long nt8 = (end - pos0 + 255) / 256;
+        const unsigned grid8 = (unsigned)(nt8 < 256 ? nt8 : 256);
+        if (hipFuncSetAttribute((const void*)gblock_fwd_bf16_kernel<false, 8>, hipFuncAttributeMaxDynamicSharedMemorySize,
+                                LDS_BYTES) != hipSuccess)
+            return MGX_ERR_LAUNCH;
+        hipLaunchKernelGGL((gblock_fwd_bf16_kernel<false, 8>), dim3(grid8), dim3(512), LDS_BYTES, st,
+                           (const unsigned char*)packb, x, y, (bf16_t*)nullptr, (long)pos0, end, hl, wl, nt8);
     } else {
-        if (hipFuncSetAttribute((const void*)gblock_fwd_bf16_kernel<false>, hipFuncAttributeMaxDynamicSharedMemorySize,
+        if (hipFuncSetAttribute((const void*)gblock_fwd_bf16_kernel<false, 4>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 LDS_BYTES) != hipSuccess)
             return MGX_ERR_LAUNCH;
-        hipLaunchKernelGGL(gblock_fwd_bf16_kernel<false>, dim3(grid), dim3(256), LDS_BYTES, st, (const unsigned char*)packb,
-                           x, y, (bf16_t*)nullptr, (long)pos0, end, hl, wl, ntiles);
+        hipLaunchKernelGGL((gblock_fwd_bf16_kernel<false, 4>), dim3(grid), dim3(256), LDS_BYTES, st,
+                           (const unsigned char*)packb, x, y, (bf16_t*)nullptr, (long)pos0, end, hl, wl, ntiles);
     }
     return mgx_launch_status();
 }
