@@ -358,6 +358,18 @@ int mgx_conv_pair_bf16_supported(int64_t nimg, int h, int w, int kb);
 int mgx_conv_pair_bf16(int64_t nimg, int h, int w, const void* x, const float* wa, const float* ba, float alpha_a,
                        const float* wb, const float* bb, float alpha_b, int kb, void* y, void* stream);
 
+/* A chain of two or three consecutive Conv2D(32, k x k, 'same') + SoftRectifier layers of a discriminator block
+ * (trainer/models.py:259-276) in one launch, for forward passes that keep no tape.  ksizes = {3,3,2}, {3,3} or
+ * {3,2} (mgx_conv_chain_bf16_supported); x and y are bf16 NHWC (nimg, h, w, 32); weights[i] / biases[i] the
+ * float32 Keras kernel (k, k, 32, 32) / bias (32) of layer i, alphas[i] its SoftRectifier alpha (> 0).  A wave
+ * streams a strip of 29-31 output columns down the rows of an image with the inner layers' rows in LDS rings:
+ * no intermediate reaches HBM and no row is computed twice.  Results are bit-identical to nlayers calls of
+ * mgx_conv_gemm_bf16. */
+int mgx_conv_chain_bf16_supported(int64_t nimg, int h, int w, int nlayers, const int* ksizes);
+int mgx_conv_chain_bf16(int64_t nimg, int h, int w, int nlayers, const int* ksizes, const void* x,
+                        const float* const* weights, const float* const* biases, const float* alphas, void* y,
+                        void* stream);
+
 /* From-audio 1x1 convolution (models.py:256): x float32 (npos, 2) -> y bf16 (npos, 128) with kernel w
  * (2,128) and bias (128) float32, optional tanh(v)+v/alpha epilogue (act_alpha > 0) and derivative
  * store (dact, bf16, may be NULL).  Its weight gradient (dw (2,128), db (128) ADDED to; g = gradient

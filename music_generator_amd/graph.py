@@ -11,6 +11,8 @@ from __future__ import annotations
 
 from typing import Dict, List, Optional, Sequence, Tuple
 
+import os
+
 import numpy as np
 import torch
 
@@ -355,6 +357,27 @@ class Model:
     # are bound by instruction issue (MFMA + activation + LDS reads), not by the HBM traffic the fusion saves,
     # and the fused tile does 1.22x the work of both layers with two more barriers.
     use_conv_pairs = False
+    # True: runs of two or three consecutive Conv2D(32) + SoftRectifier steps of a tape-free bf16 pass ({3x3, 3x3,
+    # 2x2}, {3x3, 3x3}, {3x3, 2x2}: the groups of a discriminator block) go through the row-streaming chain kernel
+    # (mgx_conv_chain_bf16; bit-identical results, the inner layers' outputs never reach HBM).
+    use_conv_chains = os.environ.get("MGX_CONV_CHAINS", "1") != "0"      # MGX_CONV_CHAINS=0: layer by layer (measurements)
+
+    def _conv_chain(self, plan, i, n_consumers, x):
+        """The longest run of plan steps starting at i that mgx_conv_chain_bf16 serves as one launch, or None."""
+        from .layers import conv_chain_eligible
+        ops_ = [plan[i]]
+        while len(ops_) < 3 and i + len(ops_) < len(plan):
+            prev, nxt = ops_[-1], plan[i + len(ops_)]
+            if (isinstance(nxt, _FusedOp) or nxt.act_node is None or len(nxt.inputs) != 1
+                    or nxt.inputs[0] is not prev.output or n_consumers.get(id(prev.output), 0) != 1
+                    or prev.output is self.output):
+                break
+            ops_.append(nxt)
+        while len(ops_) >= 2:
+            if conv_chain_eligible([o.node.layer for o in ops_], x):
+                return ops_
+            ops_.pop()
+        return None
 
     def forward(self, x, save: bool = False):
         """Run the plan.  Returns (y, tape); tape is None unless save=True."""
@@ -372,9 +395,21 @@ class Model:
         producer, n_consumers = self._plan_links(plan)
         skip = -1
         for i, op in enumerate(plan):
-            if i == skip:
+            if i <= skip:
                 continue
             xs = [vals[id(t)] for t in op.inputs]
+            if (not save and Model.use_conv_chains and not isinstance(op, _FusedOp) and op.act_node is not None
+                    and K.bf16_enabled() and xs[0].dtype == torch.bfloat16):
+                chain = self._conv_chain(plan, i, n_consumers, xs[0])
+                if chain is not None:
+                    from .layers import conv_chain_forward
+                    vals[id(chain[-1].output)] = conv_chain_forward(
+                        [o.node.layer for o in chain], [o.act_node.layer.alpha_value for o in chain], xs[0])
+                    for t in op.inputs:
+                        if last_use.get(id(t)) == i and t is not self.output:
+                            vals.pop(id(t), None)
+                    skip = i + len(chain) - 1
+                    continue
             # two consecutive convolution + activation steps whose intermediate nothing else reads run as one
             # launch when no tape is kept (bf16 path; the intermediate stays in LDS)
             if (not save and Model.use_conv_pairs and not isinstance(op, _FusedOp) and op.act_node is not None

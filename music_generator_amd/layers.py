@@ -207,6 +207,32 @@ def conv_pair_forward(a, alpha_a, b, alpha_b, x):
     return y
 
 
+def conv_chain_eligible(layers, x) -> bool:
+    """Two or three layers (each followed by a SoftRectifier) as one launch of the chain kernel: Conv2D(32, k x k,
+    same) on 32 channels with kernel sizes {3,3,2}, {3,3} or {3,2}, bf16 input, bf16 precision on."""
+    if not K.bf16_enabled() or x.dim() != 4 or x.dtype != torch.bfloat16 or x.shape[-1] != 32:
+        return False
+    if x.shape[1] < K.BF16_MIN_ROWS:
+        return False
+    ks = []
+    for l in layers:
+        if not isinstance(l, Conv2D) or l.padding != "same" or l.strides != (1, 1) or l.filters != 32 or l.cin != 32:
+            return False
+        if l.kernel_size[0] != l.kernel_size[1]:
+            return False
+        ks.append(l.kernel_size[0])
+    if tuple(ks) not in ((3, 3, 2), (3, 3), (3, 2)):
+        return False
+    return ops.conv_chain_bf16_supported(x.shape[0], x.shape[1], x.shape[2], ks)
+
+
+def conv_chain_forward(layers, alphas, x):
+    y = K.empty(tuple(x.shape), dtype=torch.bfloat16)
+    ops.conv_chain_bf16(x, [l.kernel.value() for l in layers], [l.bias.value() for l in layers], alphas,
+                        [l.kernel_size[0] for l in layers], y)
+    return y
+
+
 class _CastSaved(tuple):
     """(x, dact) of a float32 contraction whose input arrived as bf16 and was cast: the data-gradient goes
     back as bf16."""

@@ -603,6 +603,36 @@ def conv_pair_bf16(x, wa, ba, alpha_a, wb, bb, alpha_b, kb, y):
         PROFILER.stop("bpair_kernel<%d>" % kb, 2.0 * (9 + kb * kb) * 1024 * px, e0, px * 128)
 
 
+def conv_chain_bf16_supported(n, h, w, ksizes) -> bool:
+    ks = (C.c_int * len(ksizes))(*[int(k) for k in ksizes])
+    return bool(_lib().mgx_conv_chain_bf16_supported(int(n), int(h), int(w), len(ksizes), ks))
+
+
+def conv_chain_bf16(x, weights, biases, alphas, ksizes, y):
+    """mgx_conv_chain_bf16: two or three Conv2D(32, k x k, same) + SoftRectifier layers on a bf16 (n, h, w, 32)
+    tensor in one launch, no tape."""
+    n, h, w, c = x.shape
+    nl = len(ksizes)
+    if c != 32 or tuple(y.shape) != (n, h, w, 32) or x.dtype != torch.bfloat16 or y.dtype != torch.bfloat16:
+        raise MgxError("conv_chain_bf16: x and y must be bf16 (n, h, w, 32) tensors of one shape")
+    if not (len(weights) == len(biases) == len(alphas) == nl):
+        raise MgxError("conv_chain_bf16: one kernel, bias and alpha per layer")
+    for k, wt, b in zip(ksizes, weights, biases):
+        if wt.numel() != k * k * 1024 or b.numel() != 32:
+            raise MgxError("conv_chain_bf16: kernels must be (k,k,32,32), biases (32,)")
+    ks = (C.c_int * nl)(*[int(k) for k in ksizes])
+    wp = (C.c_void_p * nl)(*[_p(t) for t in weights])
+    bp = (C.c_void_p * nl)(*[_p(t) for t in biases])
+    al = (C.c_float * nl)(*[float(a) for a in alphas])
+    e0 = PROFILER.start() if PROFILER is not None else None
+    check(_lib().mgx_conv_chain_bf16(n, h, w, nl, ks, _pb(x), wp, bp, al, _pb(y), K.stream_ptr()),
+          "mgx_conv_chain_bf16")
+    if e0 is not None:
+        px = n * h * w
+        PROFILER.stop("bchain_kernel<%s>" % ",".join(str(int(k)) for k in ksizes),
+                      2.0 * sum(k * k for k in ksizes) * 1024 * px, e0, px * 128)
+
+
 def conv_wgrad_bf16(d: ConvDesc, x, g, dw, dbias):
     xe, ye, we = _conv_sizes(d)
     if x.numel() != xe or g.numel() != ye or dw.numel() < we:

@@ -621,7 +621,9 @@ def test_bf16_discriminator_forward_with_and_without_pairs(bf16_precision):
     calls = []
     orig = ops.conv_pair_bf16
     ops.conv_pair_bf16 = lambda *a, **k: (calls.append(1), orig(*a, **k))[1]
+    chains = Model.use_conv_chains
     try:
+        Model.use_conv_chains = False          # the chain kernel would take the same layers first
         Model.use_conv_pairs = True
         y1 = model(x).clone()
         n_pairs = len(calls)
@@ -633,6 +635,85 @@ def test_bf16_discriminator_forward_with_and_without_pairs(bf16_precision):
         assert len(calls) == n_pairs
     finally:
         Model.use_conv_pairs = False
+        Model.use_conv_chains = chains
         ops.conv_pair_bf16 = orig
     assert n_pairs >= 3, n_pairs
+    assert torch.equal(y0, y1), (y0, y1)
+
+
+@pytest.mark.parametrize("h,w,n,ks", [(16, 64, 1, (3, 3, 2)), (8, 29, 2, (3, 3, 2)), (9, 30, 1, (3, 3, 2)),
+                                      (20, 45, 2, (3, 3)), (32, 100, 3, (3, 2)), (48, 333, 1, (3, 3, 2)),
+                                      (17, 31, 1, (3, 2)), (64, 500, 2, (3, 3)), (2, 8, 1, (3, 3, 2)),
+                                      (33, 61, 5, (3, 3, 2))])
+def test_bf16_conv_chain_equals_separate_launches(h, w, n, ks):
+    """mgx_conv_chain_bf16 (two or three convolution + activation layers in one launch, a wave streaming a strip of
+    columns down the rows with the inner layers' rows in LDS rings) against one launch of mgx_conv_gemm_bf16 per
+    layer: the same MFMAs on the same bf16 values in the same order, so the outputs must be equal bit for bit,
+    on ragged strips (widths that are not a multiple of 29 / 30 / 31), at the image borders (zero padding of
+    EVERY layer, rows and columns) and across images (more strips than one workgroup holds)."""
+    M.clear_session()
+    layers = [L.Conv2D(32, (k, k), padding="same", kernel_initializer="he_normal") for k in ks]
+    rng = np.random.default_rng(h * 100 + w + sum(ks))
+    for layer in layers:
+        layer(Input(shape=(h, w, 32)))
+        layer.bias.assign(rng.uniform(-0.3, 0.3, (32,)).astype(np.float32))
+    x = _dev_b(rng.uniform(-1, 1, (n, h, w, 32)))
+    alphas = [7.0, 80000.0, 11000.0][:len(ks)]
+    cur = x
+    for layer, alpha in zip(layers, alphas):
+        nxt = torch.empty((n, h, w, 32), dtype=torch.bfloat16, device="cuda")
+        ops.conv_gemm_bf16(layer._desc("f", n, h, w), cur, layer.kernel.value(), layer.bias.value(), nxt, act_alpha=alpha)
+        cur = nxt
+    want = cur
+    assert ops.conv_chain_bf16_supported(n, h, w, ks)
+    got = torch.full_like(want, float("nan"))
+    ops.conv_chain_bf16(x, [l.kernel.value() for l in layers], [l.bias.value() for l in layers], alphas, ks, got)
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(got.float()).all()), "positions left unwritten"
+    diff = (got.float() - want.float()).abs()
+    where = np.unravel_index(int(diff.argmax()), tuple(diff.shape))
+    assert torch.equal(got.view(torch.int16), want.view(torch.int16)), "max abs difference %.3e at %s" % (float(diff.max()), where)
+
+
+def test_bf16_conv_chain_rejects_what_it_does_not_serve():
+    assert not ops.conv_chain_bf16_supported(1, 16, 64, (3, 3, 3))
+    assert not ops.conv_chain_bf16_supported(1, 16, 64, (2, 3))
+    assert not ops.conv_chain_bf16_supported(1, 16, 64, (3,))
+    assert not ops.conv_chain_bf16_supported(1, 16, 4, (3, 3))
+    x = torch.zeros((1, 16, 64, 32), dtype=torch.bfloat16, device="cuda")
+    w3 = torch.zeros((3, 3, 32, 32), device="cuda")
+    b = torch.zeros((32,), device="cuda")
+    with pytest.raises(ops.MgxError):
+        ops.conv_chain_bf16(x, [w3, w3], [b, b], [7.0, 0.0], (3, 3), torch.empty_like(x))     # alpha must be > 0
+    with pytest.raises(ops.MgxError):
+        ops.conv_chain_bf16(x, [w3, w3], [b, b], [7.0, 7.0], (3, 2), torch.empty_like(x))     # kernel shape mismatch
+
+
+def test_bf16_discriminator_forward_with_and_without_chains(bf16_precision):
+    """A tape-free discriminator forward (the metric passes of the step) through the chain kernel
+    (Model.use_conv_chains, the default) against the same forward layer by layer: bit-identical logits, three chains
+    per grown block that is tall enough; with a tape the chain kernel is not used."""
+    from music_generator_amd.graph import Model
+    d, g, comp, W = _build(4)
+    model = d[3][1]
+    real, _ = R.synthetic_inputs(3, 4, seed=2)
+    x = torch.from_numpy(real).cuda()
+    calls = []
+    orig = ops.conv_chain_bf16
+    ops.conv_chain_bf16 = lambda *a, **k: (calls.append(tuple(a[4])), orig(*a, **k))[1]
+    chains = Model.use_conv_chains
+    try:
+        Model.use_conv_chains = True
+        y1 = model(x).clone()
+        n_chains = len(calls)
+        Model.use_conv_chains = False
+        y0 = model(x).clone()
+        assert len(calls) == n_chains
+        Model.use_conv_chains = True
+        model.forward(x, save=True)
+        assert len(calls) == n_chains
+    finally:
+        Model.use_conv_chains = chains
+        ops.conv_chain_bf16 = orig
+    assert n_chains >= 6 and set(calls) == {(3, 2), (3, 3, 2), (3, 3)}, calls
     assert torch.equal(y0, y1), (y0, y1)
