@@ -7,8 +7,8 @@
 // 32-channel output-gradient tile (multiplied by the saved activation derivative while staging)
 // go to LDS position-major; out-of-image positions are written as zeros.  Contraction runs over
 // positions, two per MFMA: a wave owns two tile rows and keeps one 32x32 accumulator per tap for
-// the whole launch; the grid is persistent and every wave writes one slab of partial sums that
-// conv_wgrad.hip adds in fixed order.  Input chunks of 128-channel convolutions are blockIdx.y.
+// the whole launch; the grid is persistent and every workgroup writes one slab of partial sums (its
+// four waves' tiles added in LDS in wave order) that conv_wgrad.hip adds in fixed order.  Input chunks of 128-channel convolutions are blockIdx.y.
 #include "common.h"
 #include "wino.h"
 #include "../../include/mgx.h"
@@ -178,21 +178,44 @@ __global__ __launch_bounds__(256, KH * KW == 16 ? 1 : 2) void twgrad_kernel(mgx_
             }
         }
     }
-    // slabs: partial[((split*tiles_total + tile)*16 + reg)*64 + lane], split = (wg, wave),
-    // tile = (tap*kchunks + kc)*NCH + nc (32 x 32 each)
-    const long split = (long)bx * 4 + wv;
+    // One slab per WORKGROUP: partial[((split*tiles_total + tile)*16 + reg)*64 + lane], split = workgroup,
+    // tile = (tap*kchunks + kc)*NCH + nc (32 x 32 each).  The four waves' accumulator tiles are added in LDS in
+    // wave order, two tiles a round (waves 0 and 1 add one each): a slab per wave is four times the bytes the
+    // fixed-order reduction kernel has to read, and for small images that kernel was as long as this one.
+    const long split = bx;
     const long tiles_total = (long)TAPS * kchunks * NCH;
+    constexpr int NTILE = TAPS * NCH;
+    static_for<0, (NTILE + 1) / 2>([&](auto rr) {
+        constexpr int t0 = decltype(rr)::value * 2;
+        __syncthreads();                      // the tile buffers (or the previous round's tiles) are done with
 #pragma unroll
-    for (int t = 0; t < TAPS; ++t)
+        for (int j = 0; j < 2; ++j)
+            if (t0 + j < NTILE) {
 #pragma unroll
-        for (int nc = 0; nc < NCH; ++nc) {
+                for (int reg = 0; reg < 16; ++reg) lds[((j * 4 + wv) * 16 + reg) * 64 + lane] = acc[t0 + j][reg];
+            }
+        __syncthreads();
+        if (wv < 2 && t0 + wv < NTILE) {
+            const int tt = t0 + wv, t = tt / NCH, nc = tt - t * NCH;
+            const float* src = lds + (wv * 4) * 1024 + lane;
             float* dst = partial + ((split * tiles_total + ((long)t * kchunks + kc) * NCH + nc) * 16) * 64 + lane;
 #pragma unroll
-            for (int reg = 0; reg < 16; ++reg) dst[reg * 64] = acc[t * NCH + nc][reg];
+            for (int reg = 0; reg < 16; ++reg)
+                dst[reg * 64] = ((src[reg * 64] + src[1024 + reg * 64]) + src[2048 + reg * 64]) + src[3072 + reg * 64];
         }
+    });
     if (bpartial && kc == 0) {
+        __syncthreads();
 #pragma unroll
-        for (int nc = 0; nc < NCH; ++nc) bpartial[(split * NCH + nc) * 64 + lane] = bsum[nc];
+        for (int nc = 0; nc < NCH; ++nc) lds[(wv * NCH + nc) * 64 + lane] = bsum[nc];
+        __syncthreads();
+        if (wv == 0) {
+#pragma unroll
+            for (int nc = 0; nc < NCH; ++nc)
+                bpartial[(split * NCH + nc) * 64 + lane] =
+                    ((lds[nc * 64 + lane] + lds[(NCH + nc) * 64 + lane]) + lds[(2 * NCH + nc) * 64 + lane]) +
+                    lds[(3 * NCH + nc) * 64 + lane];
+        }
     }
 }
 
@@ -294,7 +317,7 @@ extern "C" int mgx_conv_route(const mgx_conv_desc* d, int wgrad) {
 long mgx_twgrad_splits(const mgx_conv_desc& d) {
     const int rt = (d.hout % TH || d.kh == 4) ? 4 : TH;
     const int tiles_h = d.hout / rt, tiles_w = (d.wout + TW - 1) / TW;
-    return (long)tile_grid((long)d.nimg * tiles_h * tiles_w) * 4;
+    return (long)tile_grid((long)d.nimg * tiles_h * tiles_w);      // one slab per workgroup
 }
 
 int mgx_twgrad_launch(const mgx_conv_desc& d, const float* x, const float* dy, const float* dymul, float* partial,
