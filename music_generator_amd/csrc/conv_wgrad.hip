@@ -342,9 +342,33 @@ __global__ __launch_bounds__(256) void dense_wgrad_kernel(mgx_conv_desc d, const
 // dW[tap*wtap + k*wsk + n*wsn] += sum_split partial[...].  A block of 1024 threads covers 64
 // consecutive elements x 16 split groups (group g adds splits g, g+16, ... in order); the 16 group
 // sums are then added in a fixed tree, so the result does not depend on scheduling.
+// Blocks wblocks and up add the bias partials instead, so that a weight gradient ends in one reduction launch,
+// not two: db[c] += sum over n == c (mod nbias), splits, lane halves; four bias elements a block, 256 threads each
+// (per-thread sums over its splits in double, wave sums, then the four waves in a fixed tree).
 __global__ __launch_bounds__(1024) void wgrad_reduce_kernel(mgx_conv_desc d, const float* __restrict__ partial,
                                                             float* __restrict__ dw, long splits, int ktot, int ntot,
-                                                            long tiles_total) {
+                                                            long tiles_total, const float* __restrict__ bpartial,
+                                                            float* __restrict__ db, int wblocks, int b_ngemm,
+                                                            int b_nbias, int b_ntot) {
+    if ((int)blockIdx.x >= wblocks) {
+        __shared__ double bred[16];
+        const int q = threadIdx.x >> 8, t = threadIdx.x & 255;
+        const int c = ((int)blockIdx.x - wblocks) * 4 + q;
+        double s = 0.0;
+        if (c < b_nbias)
+            for (int n = c; n < b_ngemm; n += b_nbias) {
+                const int nt = n >> 5, j = n & 31;
+                for (long sp = t; sp < splits; sp += 256) {
+                    const float* src = bpartial + (sp * b_ntot + nt) * 64;
+                    s += (double)src[j] + (double)src[j + 32];
+                }
+            }
+        s = wave_sum_d(s);
+        if ((threadIdx.x & 63) == 0) bred[threadIdx.x >> 6] = s;
+        __syncthreads();
+        if (t == 0 && c < b_nbias) db[c] += (float)((bred[4 * q] + bred[4 * q + 1]) + (bred[4 * q + 2] + bred[4 * q + 3]));
+        return;
+    }
     __shared__ float red[16][64];
     const int e = threadIdx.x & 63, g = threadIdx.x >> 6;
     const long idx = (long)blockIdx.x * 64 + e;
@@ -377,23 +401,6 @@ __global__ __launch_bounds__(1024) void wgrad_reduce_kernel(mgx_conv_desc d, con
             for (int q = 0; q < w; ++q) t[q] += t[q + w];
         dw[(long)tap * d.wtap + (long)k * d.wsk + (long)n * d.wsn] += t[0];
     }
-}
-
-// db[c] += sum over n == c (mod nbias), splits, lane halves; one block per bias element.
-__global__ __launch_bounds__(256) void bias_reduce_kernel(mgx_conv_desc d, const float* __restrict__ bpartial,
-                                                          float* __restrict__ db, long splits, int ntot) {
-    __shared__ double red[4];
-    const int c = blockIdx.x;
-    double s = 0.0;
-    for (int n = c; n < d.ngemm; n += d.nbias) {
-        const int nt = n >> 5, j = n & 31;
-        for (long sp = threadIdx.x; sp < splits; sp += 256) {
-            const float* src = bpartial + (sp * ntot + nt) * 64;
-            s += (double)src[j] + (double)src[j + 32];
-        }
-    }
-    const double t = block_sum256_d(s, red);
-    if (threadIdx.x == 0) db[c] += (float)t;
 }
 
 template <int T, int KT, int NT>
@@ -540,12 +547,13 @@ extern "C" int mgx_conv_wgrad_f32(const mgx_conv_desc* dp, const float* x, const
         du_desc.wtap = (int64_t)d.cin * 32;
         du_desc.wsk = 32;
         du_desc.wsn = 1;
-        hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((p.du_floats + 63) / 64)), dim3(1024), 0, st, du_desc,
-                           partial, du, p.splits, p.ktot, p.ntot, p.tiles_total);
+        {
+            const int wblocks = (int)((p.du_floats + 63) / 64), bblocks = dbias ? (d.nbias + 3) / 4 : 0;
+            hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)(wblocks + bblocks)), dim3(1024), 0, st, du_desc,
+                               partial, du, p.splits, p.ktot, p.ntot, p.tiles_total, bpartial, dbias, wblocks,
+                               (int)d.ngemm, (int)d.nbias, p.ntot);
+        }
         if (mgx_wwgrad_finish(d, du, dw, st) != MGX_OK) return MGX_ERR_LAUNCH;
-        if (dbias)
-            hipLaunchKernelGGL(bias_reduce_kernel, dim3((unsigned)d.nbias), dim3(256), 0, st, d, bpartial, dbias,
-                               p.splits, p.ntot);
         return mgx_launch_status();
     }
 #define MGX_WG(TT, KK, NN) launch_wgrad<TT, KK, NN>(d, p, x, dy, dymul, partial, bpartial, st)
@@ -575,10 +583,9 @@ extern "C" int mgx_conv_wgrad_f32(const mgx_conv_desc* dp, const float* x, const
 #undef MGX_WG
     if (hipGetLastError() != hipSuccess) return MGX_ERR_LAUNCH;
     const long total = (long)d.kh * d.kw * d.cin * d.ngemm;
-    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)((total + 63) / 64)), dim3(1024), 0, st, d, partial, dw,
-                       p.splits, p.ktot, p.ntot, p.tiles_total);
-    if (dbias)
-        hipLaunchKernelGGL(bias_reduce_kernel, dim3((unsigned)d.nbias), dim3(256), 0, st, d, bpartial, dbias, p.splits,
-                           p.ntot);
+    const int wblocks = (int)((total + 63) / 64), bblocks = dbias ? (d.nbias + 3) / 4 : 0;
+    hipLaunchKernelGGL(wgrad_reduce_kernel, dim3((unsigned)(wblocks + bblocks)), dim3(1024), 0, st, d, partial, dw,
+                       p.splits, p.ktot, p.ntot, p.tiles_total, bpartial, dbias, wblocks, (int)d.ngemm, (int)d.nbias,
+                       p.ntot);
     return mgx_launch_status();
 }
