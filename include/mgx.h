@@ -205,6 +205,12 @@ int mgx_avgpool2x_bwd(const float* dy, float* dx, int64_t nimg, int h, int w, in
 int mgx_add_n(const float* const* xs, int nin, float* y, int64_t n, void* stream);
 /* dst += src (gradient fan-in). */
 int mgx_add_inplace(float* dst, const float* src, int64_t n, void* stream);
+/* One micro-batch of whole MinibatchStdDev groups out of a batch of g * m samples (the groups of
+ * models.py:179-195 are the members m', m + m', 2m + m', ... of the batch): output sample a * cnt + b is input
+ * sample a * m + m0 + b for a < g, b < cnt, i.e. g contiguous runs of cnt samples of row_floats floats each
+ * (a multiple of 4).  Splitting train_step (models.py:72-158) into micro-batches has no counterpart in the
+ * reference; it is what lets the upper stages fit in HBM. */
+int mgx_gather_groups(const float* src, float* dst, int64_t row_floats, int g, int m, int m0, int cnt, void* stream);
 
 /* WeightedSum (models.py:30-35): y = (1-alpha)*a + alpha*b, alpha read from device memory.
  * Backward: da (+)= (1-alpha)*dy, db (+)= alpha*dy, dalpha += sum(dy*(b-a)) (if dalpha != NULL;

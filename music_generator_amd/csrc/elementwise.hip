@@ -350,6 +350,32 @@ extern "C" int mgx_add_n(const float* const* xs, int nin, float* y, int64_t n, v
     return mgx_launch_status();
 }
 
+// Micro-batch of whole MinibatchStdDev groups: output sample a * cnt + b is input sample a * m + m0 + b
+// (a < g, b < cnt): g contiguous runs of cnt samples.  blockIdx.y = output sample.
+__global__ __launch_bounds__(kBlock) void gather_groups_kernel(const float4* __restrict__ src, float4* __restrict__ dst,
+                                                               long row4, int m, int m0, int cnt) {
+    const int o = blockIdx.y, a = o / cnt, b = o - a * cnt;
+    const float4* s = src + ((long)a * m + m0 + b) * row4;
+    float4* d = dst + (long)o * row4;
+    for (long i = (long)blockIdx.x * kBlock + threadIdx.x; i < row4; i += (long)gridDim.x * kBlock)
+        d[i] = s[i];
+}
+
+extern "C" int mgx_gather_groups(const float* src, float* dst, int64_t row_floats, int g, int m, int m0, int cnt,
+                                 void* stream) {
+    if (!src || !dst || row_floats <= 0 || row_floats % 4 || g <= 0 || cnt <= 0 || m0 < 0 || m0 + cnt > m)
+        return MGX_ERR_ARG;
+    if ((long)g * cnt > 65535) return MGX_ERR_ARG;
+    const long row4 = row_floats / 4;
+    long gx = (row4 + kBlock - 1) / kBlock;
+    const long cap = (4096 + (long)g * cnt - 1) / ((long)g * cnt);      // ~4096 blocks in all
+    if (gx > cap) gx = cap;
+    if (gx < 1) gx = 1;
+    hipLaunchKernelGGL(gather_groups_kernel, dim3((unsigned)gx, (unsigned)(g * cnt)), dim3(kBlock), 0,
+                       (hipStream_t)stream, (const float4*)src, (float4*)dst, row4, m, m0, cnt);
+    return mgx_launch_status();
+}
+
 extern "C" int mgx_add_inplace(float* dst, const float* src, int64_t n, void* stream) {
     if (!dst || !src || n <= 0) return MGX_ERR_ARG;
     const long n4 = n / 4;

@@ -607,6 +607,22 @@ class History:
         self.history: Dict[str, List[float]] = {}
 
 
+class _MicroBatch:
+    """Samples a * m + m0 + b (a < g, b < cnt) of a batch of g * m: cnt whole MinibatchStdDev groups."""
+    __slots__ = ("g", "m", "m0", "cnt", "_index")
+
+    def __init__(self, g, m, m0, cnt):
+        self.g, self.m, self.m0, self.cnt, self._index = g, m, m0, cnt, None
+
+    @property
+    def index(self):
+        """The sample numbers as a device tensor (only the kept-logits diagnostics use it)."""
+        if self._index is None:
+            idx = (np.arange(self.g)[:, None] * self.m + self.m0 + np.arange(self.cnt)[None, :]).reshape(-1)
+            self._index = torch.as_tensor(idx, dtype=torch.int64, device=K.device())
+        return self._index
+
+
 class WGAN:
     def __init__(self, discriminator, generator, latent_dim, fade_in=False, discriminator_extra_steps=3,
                  gp_weight=10.0, trainable_alpha=True):
@@ -680,7 +696,7 @@ class WGAN:
 
     # -- micro-batching: whole MinibatchStdDev groups (members m, M+m, 2M+m, 3M+m), g-major --
     def _micro_batches(self, n):
-        """Index tensors of the micro-batches of a local batch of n (None = the whole batch)."""
+        """The micro-batches of a local batch of n as _MicroBatch records (None = the whole batch)."""
         mb = self.micro_batch
         if not mb or mb >= n:
             return [None]
@@ -691,17 +707,12 @@ class WGAN:
         key = (n, mb)
         if key not in self._mb_cache:
             m, per = n // g, mb // g
-            out = []
-            for m0 in range(0, m, per):
-                groups = np.arange(m0, min(m0 + per, m))
-                idx = (np.arange(g)[:, None] * m + groups[None, :]).reshape(-1)
-                out.append(torch.as_tensor(idx, dtype=torch.int64, device=K.device()))
-            self._mb_cache[key] = out
+            self._mb_cache[key] = [_MicroBatch(g, m, m0, min(per, m - m0)) for m0 in range(0, m, per)]
         return self._mb_cache[key]
 
     @staticmethod
-    def _take(t, idx):
-        return t if idx is None else t.index_select(0, idx)
+    def _take(t, mbatch):
+        return t if mbatch is None else ops.gather_groups(t, mbatch.g, mbatch.m, mbatch.m0, mbatch.cnt)
 
     def _ones(self, n):
         t = self._ones_cache.get(n)
@@ -932,7 +943,7 @@ class WGAN:
                         if item[0] is None:
                             full.copy_(item[j])
                         else:
-                            full.index_copy_(0, item[0], item[j])
+                            full.index_copy_(0, item[0].index, item[j])
                     self.last_logits[key] = full
             out_d, cf, cr = self._finish_sums(sums, 0, n, True)
             if self.dist is not None:

@@ -381,6 +381,19 @@ def add_n(xs: Sequence[torch.Tensor], y):
     check(_lib().mgx_add_n(arr, len(xs), _p(y), n, K.stream_ptr()), "mgx_add_n")
 
 
+def gather_groups(src, g, m, m0, cnt):
+    """mgx_gather_groups: samples a * m + m0 + b (a < g, b < cnt) of a float32 batch of g * m samples, a-major."""
+    if src.dtype != torch.float32 or src.shape[0] != g * m:
+        raise MgxError("gather_groups: a float32 batch of g * m samples is expected")
+    row = src.numel() // src.shape[0]
+    if row % 4:
+        raise MgxError("gather_groups: samples must be a multiple of 4 floats")
+    dst = K.empty((g * cnt,) + tuple(src.shape[1:]))
+    check(_lib().mgx_gather_groups(_p(src), _p(dst), row, int(g), int(m), int(m0), int(cnt), K.stream_ptr()),
+          "mgx_gather_groups")
+    return dst
+
+
 def add_inplace(dst, src):
     if dst.numel() != src.numel():
         raise MgxError("add_inplace: size mismatch")

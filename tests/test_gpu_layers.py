@@ -375,3 +375,20 @@ def test_evaluator_fit_matches_oracle():
     hist = E.fit_evaluator(model, x, y, epochs=3, batch_size=4, optimizer=M.Adam(lr=1e-5), validation_data=(x, y))
     assert [len(hist[k]) for k in ("loss", "accuracy", "val_loss", "val_accuracy")] == [3, 3, 3, 3]
     assert np.isfinite(hist["loss"]).all() and hist["val_loss"][-1] < hist["val_loss"][0]
+
+
+@pytest.mark.parametrize("g,m,per,shape", [(4, 4, 1, (4, 8, 2)), (4, 16, 4, (8, 100, 2)), (4, 6, 4, (4, 750, 2)),
+                                           (2, 3, 2, (1, 100, 2)), (1, 5, 2, (4, 2))])
+def test_gather_groups_takes_whole_minibatch_stddev_groups(g, m, per, shape):
+    """mgx_gather_groups against an index gather: micro-batch k holds samples a * m + m0 + b (a < g, b < cnt),
+    a-major, including the short last micro-batch (m not a multiple of the groups per micro-batch)."""
+    from music_generator_amd import ops
+    rng = np.random.default_rng(g * 100 + m)
+    x = torch.from_numpy(rng.standard_normal((g * m,) + shape).astype(np.float32)).cuda()
+    for m0 in range(0, m, per):
+        cnt = min(per, m - m0)
+        idx = (np.arange(g)[:, None] * m + m0 + np.arange(cnt)[None, :]).reshape(-1)
+        got = ops.gather_groups(x, g, m, m0, cnt)
+        assert torch.equal(got, x[torch.as_tensor(idx, device="cuda")])
+    with pytest.raises(ops.MgxError):
+        ops.gather_groups(x, g, m, m - 1, 2)          # the run would leave its group block
