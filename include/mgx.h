@@ -392,6 +392,12 @@ int mgx_pointwise_to2_bf16(const void* g, const float* w, float* dx, int64_t npo
 int mgx_weighted_sum_bf16_fwd(const void* a, const void* b, const float* alpha, void* y, int64_t n, void* stream);
 int mgx_weighted_sum_bf16_bwd(const void* dy, const void* a, const void* b, const float* alpha, void* da, void* db,
                               float* dalpha, void* workspace, int64_t workspace_bytes, int64_t n, void* stream);
+/* The same with the gradients multiplied by the saved activation derivatives of the layers that produced a and b
+ * (ma, mb: bf16, n elements, either may be NULL): da = bf16(bf16((1-alpha) dy) * ma), db likewise, which is what a
+ * multiply pass of its own over da / db would leave. */
+int mgx_weighted_sum_bf16_bwd_mul(const void* dy, const void* a, const void* b, const float* alpha, void* da, void* db,
+                                  float* dalpha, const void* ma, const void* mb, void* workspace,
+                                  int64_t workspace_bytes, int64_t n, void* stream);
 
 /* The generator grow block of mgx_gblock_fwd_f32 / _dgrad_f32 / _wgrad_f32 (add_generator_block,
  * models.py:362-399, and its part of tape.gradient, models.py:144-146) on bf16 MFMAs with float32

@@ -131,6 +131,7 @@ PROTOTYPES = {
     "mgx_pointwise_to2_bf16": (_I, [_P, _P, _P, _I64, _I, _P]),
     "mgx_weighted_sum_bf16_fwd": (_I, [_P, _P, _P, _P, _I64, _P]),
     "mgx_weighted_sum_bf16_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I64, _I64, _P]),
+    "mgx_weighted_sum_bf16_bwd_mul": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _I64, _P]),
     "mgx_gblock_pack_bf16_bytes": (_I64, []),
     "mgx_gblock_packt_bf16_bytes": (_I64, []),
     "mgx_gblock_side_elems_bf16": (_I64, [_I64]),

@@ -207,7 +207,11 @@ __global__ __launch_bounds__(kBlock) void wsum_b_fwd_kernel(const bf16_t* __rest
 __global__ __launch_bounds__(kBlock) void wsum_b_bwd_kernel(const bf16_t* __restrict__ dy, const bf16_t* __restrict__ a,
                                                             const bf16_t* __restrict__ b, const float* __restrict__ alpha,
                                                             bf16_t* __restrict__ da, bf16_t* __restrict__ db,
-                                                            double* __restrict__ part, long n8) {
+                                                            double* __restrict__ part, long n8,
+                                                            const bf16_t* __restrict__ ma,
+                                                            const bf16_t* __restrict__ mb) {
+    // ma / mb: the saved activation derivative of the layer that produced a / b.  The gradient leaves as
+    // bf16(bf16((1 - alpha) dy) * ma): rounded where a multiply launch of its own would have rounded it.
     __shared__ double red[4];
     const float al = alpha[0], om = 1.0f - al;
     float s = 0.f;
@@ -217,12 +221,22 @@ __global__ __launch_bounds__(kBlock) void wsum_b_bwd_kernel(const bf16_t* __rest
             u32x4 o;
 #pragma unroll
             for (int k = 0; k < 4; ++k) o[k] = bf_pack(om * bf_lo(g[k]), om * bf_hi(g[k]));
+            if (ma) {
+                const u32x4 m = ((const u32x4*)ma)[i];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) o[k] = bf_pack(bf_lo(o[k]) * bf_lo(m[k]), bf_hi(o[k]) * bf_hi(m[k]));
+            }
             ((u32x4*)da)[i] = o;
         }
         if (db) {
             u32x4 o;
 #pragma unroll
             for (int k = 0; k < 4; ++k) o[k] = bf_pack(al * bf_lo(g[k]), al * bf_hi(g[k]));
+            if (mb) {
+                const u32x4 m = ((const u32x4*)mb)[i];
+#pragma unroll
+                for (int k = 0; k < 4; ++k) o[k] = bf_pack(bf_lo(o[k]) * bf_lo(m[k]), bf_hi(o[k]) * bf_hi(m[k]));
+            }
             ((u32x4*)db)[i] = o;
         }
         if (part) {
@@ -340,14 +354,23 @@ extern "C" int mgx_weighted_sum_bf16_fwd(const void* a, const void* b, const flo
 extern "C" int mgx_weighted_sum_bf16_bwd(const void* dy, const void* a, const void* b, const float* alpha, void* da,
                                          void* db, float* dalpha, void* workspace, int64_t workspace_bytes, int64_t n,
                                          void* stream) {
+    return mgx_weighted_sum_bf16_bwd_mul(dy, a, b, alpha, da, db, dalpha, nullptr, nullptr, workspace, workspace_bytes,
+                                         n, stream);
+}
+
+extern "C" int mgx_weighted_sum_bf16_bwd_mul(const void* dy, const void* a, const void* b, const float* alpha, void* da,
+                                             void* db, float* dalpha, const void* ma, const void* mb, void* workspace,
+                                             int64_t workspace_bytes, int64_t n, void* stream) {
     if (!dy || !alpha || n <= 0 || n % 8) return MGX_ERR_ARG;
+    if ((ma && !da) || (mb && !db)) return MGX_ERR_ARG;
     if (dalpha && (!a || !b || !workspace)) return MGX_ERR_ARG;
     if (dalpha && workspace_bytes < (int64_t)(kMaxGrid * sizeof(double))) return MGX_ERR_WORKSPACE;
     const unsigned grid = grid_for(n / 8);
     double* part = dalpha ? (double*)workspace : nullptr;
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(wsum_b_bwd_kernel, dim3(grid), dim3(kBlock), 0, st, (const bf16_t*)dy, (const bf16_t*)a,
-                       (const bf16_t*)b, alpha, (bf16_t*)da, (bf16_t*)db, part, (long)(n / 8));
+                       (const bf16_t*)b, alpha, (bf16_t*)da, (bf16_t*)db, part, (long)(n / 8), (const bf16_t*)ma,
+                       (const bf16_t*)mb);
     if (dalpha) hipLaunchKernelGGL(finish_sum_b_kernel, dim3(1), dim3(64), 0, st, part, (int)grid, dalpha);
     return mgx_launch_status();
 }

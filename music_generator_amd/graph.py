@@ -530,6 +530,14 @@ class Model:
                 outmul = tape[j] if (j is not None and n_consumers.get(id(op.inputs[0])) == 1
                                      and hasattr(tape[j], "premultiplied")) else None
                 res = op.node.layer.backward(tape[i], g[0], need, existing, need_weight_grads, outmul=outmul)
+            elif getattr(op.node.layer, "takes_outmuls", False):
+                # WeightedSum: the same for each of its inputs
+                oms = []
+                for t in op.inputs:
+                    j = producer.get(id(t))
+                    oms.append(tape[j] if (j is not None and n_consumers.get(id(t)) == 1
+                                           and hasattr(tape[j], "premultiplied")) else None)
+                res = op.node.layer.backward(tape[i], g[0], need, existing, need_weight_grads, outmuls=oms)
             else:
                 res = op.node.layer.backward(tape[i], g[0], need, existing, need_weight_grads)
             tape[i] = None

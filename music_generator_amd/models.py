@@ -55,7 +55,10 @@ class WeightedSum(Add):
     def forward(self, xs, save):
         return self._merge_function(xs), ((xs[0], xs[1]) if save else None)
 
-    def backward(self, saved, dy, need, existing, wgrad):
+    # the executor hands backward() the tape entries of the layers that produced the two inputs (outmuls)
+    takes_outmuls = True
+
+    def backward(self, saved, dy, need, existing, wgrad, outmuls=(None, None)):
         a, b = saved
         dalpha = self.alpha.grad if (wgrad and self.trainable and self.alpha.trainable) else None
         if dalpha is None and wgrad and self.trainable and self.alpha.trainable:
@@ -66,7 +69,13 @@ class WeightedSum(Add):
             g = dy if dy.dtype == torch.bfloat16 else ops.cast_to_bf16(dy)
             da = K.empty(a.shape, dtype=torch.bfloat16) if need[0] else None
             db = K.empty(b.shape, dtype=torch.bfloat16) if need[1] else None
-            ops.weighted_sum_bf16_bwd(g, a, b, self.alpha.value(), da, db, dalpha)
+            # a producer's saved activation derivative is applied here instead of in a multiply launch of its own
+            mul = [None, None]
+            for k, (om, d_) in enumerate(zip(outmuls, (da, db))):
+                if d_ is not None and om is not None and om.dact is not None and not om.premultiplied:
+                    mul[k] = om.dact
+                    om.premultiplied = True
+            ops.weighted_sum_bf16_bwd(g, a, b, self.alpha.value(), da, db, dalpha, ma=mul[0], mb=mul[1])
             return [(da, True) if da is not None else None, (db, True) if db is not None else None]
         mixed = (a.dtype, b.dtype)
         if a.dtype != b.dtype:

@@ -700,15 +700,17 @@ def weighted_sum_bf16_fwd(a, b, alpha, y):
 
 
 @_hbm_op("wsum_bf16_bwd")
-def weighted_sum_bf16_bwd(dy, a, b, alpha, da, db, dalpha):
+def weighted_sum_bf16_bwd(dy, a, b, alpha, da, db, dalpha, ma=None, mb=None):
+    """ma / mb: saved activation derivatives of the producers of a / b; da / db leave multiplied by them."""
     n = dy.numel()
-    for t in (a, b, da, db):
+    for t in (a, b, da, db, ma, mb):
         if t is not None and t.numel() != n:
             raise MgxError("weighted_sum_bf16_bwd: size mismatch")
     lib = _lib()
     ws = K.workspace(lib.mgx_reduce_workspace())
-    check(lib.mgx_weighted_sum_bf16_bwd(_pb(dy), _pb(a), _pb(b), _p(alpha), _pb(da), _pb(db), _p(dalpha),
-                                        ws.data_ptr(), ws.numel(), n, K.stream_ptr()), "mgx_weighted_sum_bf16_bwd")
+    check(lib.mgx_weighted_sum_bf16_bwd_mul(_pb(dy), _pb(a), _pb(b), _p(alpha), _pb(da), _pb(db), _p(dalpha), _pb(ma),
+                                            _pb(mb), ws.data_ptr(), ws.numel(), n, K.stream_ptr()),
+          "mgx_weighted_sum_bf16_bwd_mul")
 
 
 def gblock_pack_bf16_bytes() -> int:

@@ -717,3 +717,24 @@ def test_bf16_discriminator_forward_with_and_without_chains(bf16_precision):
         ops.conv_chain_bf16 = orig
     assert n_chains >= 6 and set(calls) == {(3, 2), (3, 3, 2), (3, 3)}, calls
     assert torch.equal(y0, y1), (y0, y1)
+
+
+def test_bf16_weighted_sum_backward_applies_producer_derivatives():
+    """mgx_weighted_sum_bf16_bwd_mul against mgx_weighted_sum_bf16_bwd followed by one multiply launch per input
+    (what the executor did before): bit-identical gradients, the same alpha gradient, either multiplier optional."""
+    rng = np.random.default_rng(11)
+    shape = (2, 8, 100, 128)
+    dy, a, b, ma, mb = (_dev_b(rng.uniform(-1, 1, shape)) for _ in range(5))
+    alpha = torch.tensor([0.37], device="cuda")
+    da0, db0 = torch.empty_like(a), torch.empty_like(b)
+    dal0 = torch.zeros((1,), device="cuda")
+    ops.weighted_sum_bf16_bwd(dy, a, b, alpha, da0, db0, dal0)
+    want_a, want_b = ops.mul_bf16(da0, ma), ops.mul_bf16(db0, mb)
+    for use_a, use_b in ((True, True), (True, False), (False, True)):
+        da1, db1 = torch.empty_like(a), torch.empty_like(b)
+        dal1 = torch.zeros((1,), device="cuda")
+        ops.weighted_sum_bf16_bwd(dy, a, b, alpha, da1, db1, dal1, ma=ma if use_a else None, mb=mb if use_b else None)
+        torch.cuda.synchronize()
+        assert torch.equal(da1, want_a if use_a else da0)
+        assert torch.equal(db1, want_b if use_b else db0)
+        assert torch.equal(dal1, dal0)
