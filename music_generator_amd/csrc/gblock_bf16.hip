@@ -330,12 +330,15 @@ __global__ __launch_bounds__(64 * NW, 1) void gblock_fwd_bf16_kernel(const unsig
                         o3b[ot] = to_b(o3);
                         if (SAVE) save_b<2>(abr, GB_O3 + (A * 2 + b) * 64 + ot * 32, o3b[ot], r, h, tl);
                     }
+                    // the four output tiles innermost: an MFMA that continues the accumulator of the one before it
+                    // issues after 39 cycles instead of 32 (measured, also with a second wave on the SIMD); every
+                    // accumulator still receives its four products in the same order
 #pragma unroll
-                    for (int ot = 0; ot < 4; ++ot)
+                    for (int it = 0; it < 2; ++it)
 #pragma unroll
-                        for (int it = 0; it < 2; ++it)
+                        for (int ks = 0; ks < 2; ++ks)
 #pragma unroll
-                            for (int ks = 0; ks < 2; ++ks)
+                            for (int ot = 0; ot < 4; ++ot)
                                 if (SAVE)       // the taped kernel is short of vector registers (tape stores): measured
                                     mfma_bf16_pinned(S[b][ot], frag(wb, FB_D2 + (ot * 2 + it) * 2 + ks, lane), o3b[it].k[ks]);
                                 else            // 380 -> 482 TFLOP/s pinned; the plain forward loses with it (831 -> 813)
