@@ -1,6 +1,7 @@
 // Micro-benchmark: how much vector-ALU / transcendental / LDS work of ONE wave hides behind its own
 // bf16 MFMAs (v_mfma_f32_32x32x16_bf16, 8 passes = 32 cycles) on gfx950, and the same with two waves per SIMD.
 //   hipcc -O3 --offload-arch=gfx950 tools/micro/issue_overlap.hip -o tools/micro/issue_overlap && ./issue_overlap
+// -DPROBE_F32 builds the same probes behind v_mfma_f32_32x32x2_f32 (16 passes = 64 cycles).
 // Prints cycles per loop iteration (s_memtime based wall clock / iterations) for k = 0..12 extra instructions.
 #include <hip/hip_runtime.h>
 #include <cstdio>
@@ -32,8 +33,13 @@ __global__ __launch_bounds__(512) void probe(float* out, int iters) {
     for (int it = 0; it < iters; ++it) {
 #pragma unroll
         for (int m = 0; m < NM; ++m) {
+#ifdef PROBE_F32
+            if ((m & 1) && MODE != 5) acc1 = __builtin_amdgcn_mfma_f32_32x32x2f32(c1, c2, acc1, 0, 0, 0);
+            else acc0 = __builtin_amdgcn_mfma_f32_32x32x2f32(c1, c2, acc0, 0, 0, 0);
+#else
             if ((m & 1) && MODE != 5) acc1 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc1, 0, 0, 0);
             else acc0 = __builtin_amdgcn_mfma_f32_32x32x16_bf16(a, b, acc0, 0, 0, 0);
+#endif
 #pragma unroll
             for (int k = 0; k < K; ++k) {
                 if (MODE == 0 || MODE == 5) asm volatile("v_fma_f32 %0, %0, %1, %2" : "+v"(v[k]) : "v"(c1), "v"(c2));
