@@ -226,6 +226,13 @@ def side_buffers(nfloats: int):
     return cur
 
 
+def available_bytes():
+    """(bytes a new allocation can still get: free device memory plus what the caching allocator holds unused,
+    total device memory)."""
+    free, total = torch.cuda.mem_get_info()
+    return free + torch.cuda.memory_reserved() - torch.cuda.memory_allocated(), total
+
+
 def empty(shape, dev=None, dtype=torch.float32) -> torch.Tensor:
     return torch.empty(tuple(int(s) for s in shape), dtype=dtype, device=dev or device())
 

@@ -152,6 +152,8 @@ class FusedGroup:
     # Upper bound in bytes for the block-sized scratch a group may hold from a taped forward to its
     # backward (None: no bound).  Groups that would exceed it keep only their input and re-compute.
     side_budget_bytes = None
+    # without a bound the taped forward checks the free memory once its tape exceeds this many bytes
+    auto_budget_from_bytes = 4 << 30
 
     def __init__(self, input: KTensor, output: KTensor, nodes: List[Node], optional_nodes: List[Node], run):
         self.input, self.output, self.nodes, self.optional_nodes, self.run = input, output, nodes, optional_nodes, run

@@ -323,18 +323,26 @@ def _register_fused_block(block_end, upsampling, for_sum_layer):
         bf = K.bf16_enabled()
         side = ops.gblock_side_elems_bf16(n * hl * wl) if bf else ops.gblock_side_floats(n * hl * wl)
         budget = FusedGroup.side_budget_bytes
-        if budget is not None and (2 if bf else 4) * side > budget:
-            return run(x), (None, x, (n, hl, wl), bf)
+        side_bytes = (2 if bf else 4) * side
+        if budget is None and side_bytes > FusedGroup.auto_budget_from_bytes:
+            # no bound given: keep the tape only if it and the gradient side buffer of the same size the backward
+            # will want leave room (the full-resolution stage at the reference's batch of 2 needs 2 x 94 GiB in
+            # float32); otherwise bound both to 1/16 of the device memory and re-compute
+            avail, total = K.available_bytes()
+            if 2 * side_bytes > 0.6 * avail:
+                budget = max(total // 16, 1 << 20)
+        if budget is not None and side_bytes > budget:
+            return run(x), (None, x, (n, hl, wl), bf, budget)
         y = K.empty((n, 2 * hl, 2 * wl, 2))
         act = K.empty((side,), dtype=torch.bfloat16 if bf else torch.float32)
         if bf:
             ops.gblock_fwd_bf16(w, packb(x), x, y, n, hl, wl, act=act)
         else:
             ops.gblock_fwd(w, state["pack"], x, y, n, hl, wl, act=act)
-        return y, (act, None, (n, hl, wl), bf)
+        return y, (act, None, (n, hl, wl), bf, None)
 
     def backward(saved, dy, need_weight_grads):
-        act, x, (n, hl, wl), bf = saved
+        act, x, (n, hl, wl), bf, budget = saved
         w = weights()
         if bf:
             if "packtb" not in state:
@@ -366,7 +374,7 @@ def _register_fused_block(block_end, upsampling, for_sum_layer):
         # re-computation: ranges of positions sized so that both side buffers fit the budget
         esize = 2 if bf else 4
         per_pos = esize * side_of(128) // 128
-        step = max(128, (FusedGroup.side_budget_bytes // (2 * per_pos)) // 128 * 128)
+        step = max(128, (budget // (2 * per_pos)) // 128 * 128)
         step = min(step, (total + 127) // 128 * 128)
         elems = side_of(step)
         bufs = K.side_buffers((elems + 1) // 2 if bf else elems)
@@ -787,6 +795,10 @@ class WGAN:
 
     GRAPH_AUTO_BATCH = 16
     OVERLAP_AUTO_BATCH = 16
+    # the automatic graph mode stops below the full-resolution stage (batch x rows x columns of the audio): a
+    # captured step keeps its activations in a memory pool of its own, which at 256 x 48000 does not fit beside
+    # the eager step's, and a step of a second gains nothing from replay
+    GRAPH_AUTO_POSITIONS = 8 << 20
 
     def _overlap(self, n) -> bool:
         """Whether the discriminator passes over the real batch run on the second stream beside the passes
@@ -800,7 +812,8 @@ class WGAN:
     def _graph_wanted(self, real) -> bool:
         if self.use_graph is not None:
             return bool(self.use_graph)
-        return (real.shape[0] <= self.GRAPH_AUTO_BATCH and self.dist is None and self.d_steps == 1
+        return (real.shape[0] <= self.GRAPH_AUTO_BATCH and real.numel() // 2 <= self.GRAPH_AUTO_POSITIONS
+                and self.dist is None and self.d_steps == 1
                 and not self._latents and ops.PROFILER is None and not self.keep_logits
                 and not self.micro_batch and not torch.cuda.is_current_stream_capturing())
 

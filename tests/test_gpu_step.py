@@ -349,7 +349,8 @@ def test_bench_workload_micro_batched_equals_whole_batch():
 
 @pytest.mark.parametrize("stage,fade,batch,budget", [(0, False, 1, None), (0, False, 5, None), (0, False, 37, None),
                                                      (1, False, 1, None), (1, True, 4, None), (2, True, 3, None),
-                                                     (2, True, 3, 48 << 20), (1, False, 1, 1 << 20)])
+                                                     (2, True, 3, 48 << 20), (1, False, 1, 1 << 20),
+                                                     (2, True, 3, "auto")])
 def test_fused_generator_backward_matches_layerwise(stage, fade, batch, budget):
     """The fused grow-block kernels (saving forward, register-chained data gradient, tile-major
     weight gradients) against the layer-by-layer taped path on the same device: output abs 2e-5 x max|y|,
@@ -359,6 +360,7 @@ def test_fused_generator_backward_matches_layerwise(stage, fade, batch, budget):
     generator (latent -> Dense(32) of the four branches in one launch, its 34 gradient tensors and d/dz in two);
     batch 37 gives its backward waves several columns each and a ragged last pass."""
     from music_generator_amd.graph import FusedGroup, Model
+    from music_generator_amd import backend as K
     n_blocks = stage + 1
     d, g, comp, W = build(n_blocks)
     model = g[stage][1 if fade else 0]
@@ -370,9 +372,14 @@ def test_fused_generator_backward_matches_layerwise(stage, fade, batch, budget):
     rng = np.random.default_rng(3)
     dy = torch.tensor(rng.standard_normal((batch,) + tuple(model.output.shape[1:])).astype(np.float32), device="cuda")
     results = []
+    auto = budget == "auto"        # no bound given and (pretended) too little free memory: the bound is chosen
+    avail_fn, auto_from = K.available_bytes, FusedGroup.auto_budget_from_bytes
     for fused in (False, True):
         Model.use_fused_backward = fused
-        FusedGroup.side_budget_bytes = budget
+        FusedGroup.side_budget_bytes = None if auto else budget
+        if auto:
+            FusedGroup.auto_budget_from_bytes = 0
+            K.available_bytes = lambda: (1 << 20, 16 << 20)
         try:
             model.bind_grads().zero_()
             y, tape = model.forward(z4[0], save=True)
@@ -381,6 +388,8 @@ def test_fused_generator_backward_matches_layerwise(stage, fade, batch, budget):
         finally:
             Model.use_fused_backward = True
             FusedGroup.side_budget_bytes = None
+            FusedGroup.auto_budget_from_bytes = auto_from
+            K.available_bytes = avail_fn
         results.append((y.cpu().numpy(), dz.cpu().numpy(),
                         {v.name: v.grad.cpu().numpy().copy() for v in model.trainable_variables}))
     (y0, dz0, g0), (y1, dz1, g1) = results
