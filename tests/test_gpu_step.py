@@ -621,6 +621,47 @@ def test_real_pass_on_second_stream_changes_nothing(stage, fade, use_graph):
         assert np.array_equal(a, b)
 
 
+@pytest.mark.parametrize("stage,fade,n,use_graph", [(0, False, 16, False), (1, True, 8, False), (2, True, 4, True),
+                                                    (1, False, 2, False)])
+def test_merged_discriminator_passes_equal_separate_passes(stage, fade, n, use_graph):
+    """WGAN.merge_passes (opt-in, for whole batches of 16 and fewer): the generated and the real batch go
+    through the discriminator as ONE pass of 2n samples, MinibatchStdDev keeping the two apart, and the backward
+    is seeded with the per-sample loss derivative instead of unit seeds that are combined afterwards.  The same
+    passes over the same data in another float32 summation order: with the learning rates at 0 (a first Adam
+    update is sign-like) metrics abs 1e-5, discriminator gradients rel-L2 5e-5 (alpha 5e-4), generator
+    gradients 2e-3; and one real step each must leave finite, equal-to-1e-5 metrics."""
+    runs = []
+    for merge in (False, True):
+        d, g, comp, _ = build(stage + 1)
+        gan = comp[stage][1 if fade else 0]
+        gan.seed(31)
+        gan.use_graph = use_graph
+        gan.merge_passes = merge
+        gan.set_train_steps(4)
+        assert gan._merge(n) == merge
+        lrs = gan.d_optimizer.lr, gan.g_optimizer.lr
+        gan.d_optimizer.lr = gan.g_optimizer.lr = 0.0
+        real, _ = R.synthetic_inputs(stage, n, seed=12)
+        for _ in range(3 if use_graph else 1):          # eager, capture, replay
+            m = {k: float(v) for k, v in gan.train_step(real).items()}
+        grads = {v.name: v.grad.cpu().numpy().copy() for model in (gan.discriminator, gan.generator)
+                 for v in model.trainable_variables}
+        d_names = {v.name for v in gan.discriminator.trainable_variables}
+        gan.d_optimizer.lr, gan.g_optimizer.lr = lrs
+        gan.use_graph = False
+        m2 = {k: float(v) for k, v in gan.train_step(real).items()}
+        runs.append((m, grads, m2))
+    (m_a, g_a, m2_a), (m_b, g_b, m2_b) = runs
+    for k in m_a:
+        assert np.isfinite(m_b[k]) and abs(m_a[k] - m_b[k]) < 1e-5, (k, m_a[k], m_b[k])
+        assert np.isfinite(m2_b[k]) and abs(m2_a[k] - m2_b[k]) < 5e-4, (k, m2_a[k], m2_b[k])
+    for k, v in g_a.items():
+        if np.abs(v).max() < 1e-12:
+            continue
+        tol = (5e-4 if k.endswith("/alpha") else 5e-5) if k in d_names else 2e-3
+        assert rel_l2(g_b[k], v) < tol, "%s: %.3e" % (k, rel_l2(g_b[k], v))
+
+
 def test_graph_survives_scratch_reallocation():
     """A captured graph carries the raw addresses of the library's scratch buffers.  Shape A is stepped twice
     (eager, then captured), a larger shape B follows and the workspace is grown beyond anything seen so far
