@@ -239,6 +239,9 @@ __global__ __launch_bounds__(64 * WAVES) void bchain_kernel(ChainDesc d, const b
                 }
         };
         batch(0, cur, wa);
+        // the wave in its MFMA phase issues first, the activation phase of the SIMD's other wave fills in behind it
+        // (measured on the three-layer chain at 64 x 32 x 6000: 1.05 -> 0.90 ms)
+        __builtin_amdgcn_s_setprio(1);
 #pragma unroll
         for (int a = 0; a < KK; ++a) {
             if (a + 1 < KK) batch(a + 1, nxt, wn);
@@ -255,6 +258,7 @@ __global__ __launch_bounds__(64 * WAVES) void bchain_kernel(ChainDesc d, const b
                 }
             }
         }
+        __builtin_amdgcn_s_setprio(0);
     };
     const float ia0 = 1.0f / d.alpha[0], k10 = 1.0f + ia0;
     const float ia1 = 1.0f / d.alpha[1], k11 = 1.0f + ia1;
