@@ -149,10 +149,10 @@ _workspace: Dict[Tuple[int, int], torch.Tensor] = {}
 
 # Lane 0 is the stream the caller made current; lane 1 is the device's second stream, on which WGAN's step
 # runs the pass over the real batch beside the pass over the generated one when a batch is too small to fill
-# the chip.  Scratch buffers are per lane: the kernels of one lane are ordered by its stream, the two lanes
+# the chip; lane 2 a third one for generator forwards that can run ahead.  Scratch buffers are per lane: the kernels of one lane are ordered by its stream, the two lanes
 # are not ordered against each other between fork() and join().
 _lane = [0]
-_lane_streams: Dict[int, "torch.cuda.Stream"] = {}
+_lane_streams: Dict[Tuple[int, int], "torch.cuda.Stream"] = {}
 
 
 class _SideLane:
@@ -160,14 +160,17 @@ class _SideLane:
     one; `lane.join()` (called outside the block) makes the current stream wait for that work.  Also valid
     under HIP graph capture, where it becomes a fork / join of the captured graph."""
 
-    def __init__(self):
+    def __init__(self, lane: int = 1):
+        if lane < 1:
+            raise ValueError("side lanes are numbered from 1")
         dev = device()
-        key = dev.index or 0
+        key = (dev.index or 0, lane)
         st = _lane_streams.get(key)
         if st is None:
             st = torch.cuda.Stream(device=dev)
             _lane_streams[key] = st
         self.stream = st
+        self.lane = lane
         self._ctx = None
 
     def __enter__(self):
@@ -176,7 +179,7 @@ class _SideLane:
         self.stream.wait_stream(torch.cuda.current_stream())
         self._ctx = torch.cuda.stream(self.stream)
         self._ctx.__enter__()
-        _lane[0] = 1
+        _lane[0] = self.lane
         return self
 
     def __exit__(self, *exc):
@@ -188,8 +191,10 @@ class _SideLane:
         torch.cuda.current_stream().wait_stream(self.stream)
 
 
-def fork() -> _SideLane:
-    return _SideLane()
+def fork(lane: int = 1) -> _SideLane:
+    """Lane 1 carries the passes over the real batch; lane 2 the generator forwards of the later parts of a step
+    that only need the generator's present weights."""
+    return _SideLane(lane)
 
 
 def workspace(nbytes: int) -> torch.Tensor:

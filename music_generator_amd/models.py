@@ -688,6 +688,9 @@ class WGAN:
         # True: whole batches of up to MERGE_AUTO_BATCH samples hand the discriminator the generated and the real
         # batch as one pass of 2n samples (see _merge: faster eagerly at the low stages, slower as a replayed graph)
         self.merge_passes = False
+        # True (default): in the small-batch step (see _overlap) the generator forwards of metric block 0 and of the
+        # generator update run on a third stream beside the discriminator update
+        self.early_generator = True
         self._both: Dict = {}                 # (2n, H, W, 2) input buffers of the merged passes, by batch shape
         self._graphs: Dict = {}
         self._scalars = None                  # device [alpha, lr_t of D, lr_t of G] while capturing
@@ -766,11 +769,12 @@ class WGAN:
         ops.wgan_loss(sums, n_global, mode, out4, dfake, dreal, 1 if want_coef else 0)
         return out4, dfake, dreal
 
-    def _metric_block(self, real, n, batches, real_sum=None):
+    def _metric_block(self, real, n, batches, real_sum=None, fake=None):
         """models.py:124-130 / 150-156: fresh latents, forward only.  `real_sum` (1 float on the
-        device) replaces the real pass with an already known sum of real logits."""
+        device) replaces the real pass with an already known sum of real logits; `fake`: the generated batch of
+        this block, already computed (whole batch only)."""
         D, G = self.discriminator, self.generator
-        z = self._draw(n)
+        z = self._draw(n) if fake is None else None
         sums = K.zeros((2,))
         for idx in batches:
             lane = real_logits = None
@@ -778,7 +782,7 @@ class WGAN:
                 lane = K.fork()
                 with lane:
                     real_logits = D(self._take(real, idx)).view(-1)
-            fake_logits = D(G(self._take(z, idx)))
+            fake_logits = D(G(self._take(z, idx)) if fake is None else fake)
             if lane is not None:
                 lane.join()
             elif real_sum is None:
@@ -882,7 +886,7 @@ class WGAN:
         # scratch buffers whose addresses its launches carry
         key = (tuple(real.shape), self.micro_batch, self.generator_chunk, self.reuse_real_logits,
                FusedGroup.side_budget_bytes, K.precision(), self._overlap(real.shape[0]),
-               self._merge(real.shape[0]))
+               self._merge(real.shape[0]), self.early_generator)
         entry = self._graphs.get(key)
         alpha = self._fade_alpha()
         if entry is None:                       # first sight of this shape: ordinary step, caches warm up
@@ -941,8 +945,21 @@ class WGAN:
         batches = self._micro_batches(n)
 
         # ---- discriminator update(s) ----
+        early = (self.early_generator and self._overlap(n) and self.d_steps == 1 and batches == [None]
+                 and not self.generator_chunk)
+        lane_g = early_fake = early_gen = early_tape = None
         for _ in range(self.d_steps):
             z = self._draw(n)
+            if early:
+                # The generated batches of metric block 0 and of the generator update only need the generator as it
+                # is now (the discriminator update does not touch it): they are drawn now, in the order the step
+                # draws them anyway, and computed on a third stream beside the discriminator update, which leaves
+                # CUs idle at these sizes.
+                z_m0, z_g = self._draw(n), self._draw(n)
+                lane_g = K.fork(2)
+                with lane_g:
+                    early_fake, _ = G.forward(z_m0, save=False)
+                    early_gen, early_tape = G.forward(z_g, save=True)
             flat_f = D.bind_grads(0)
             flat_f.zero_()
             flat_r = D.bind_grads(1)
@@ -1016,24 +1033,30 @@ class WGAN:
             for idx in batches:
                 ops.logit_sums(None, D(self._take(real, idx)).view(-1), rs, accumulate=True)
             real_sum = rs[1:2].clone()           # local sum; the all-reduce happens with the fake sums
-        m0 = self._metric_block(real, n, batches, real_sum)
+        if early:
+            lane_g.join()
+        m0 = self._metric_block(real, n, batches, real_sum, fake=early_fake)
+        del early_fake
 
         # ---- generator update ----
-        z = self._draw(n)
+        z = None if early else self._draw(n)
         flat_g = G.bind_grads(0)
         flat_g.zero_()
         sums = K.zeros((2,))
         pending_g = None
         for bi, idx in enumerate(batches):
-            zb, rb = self._take(z, idx), self._take(real, idx)
-            nb = zb.shape[0]
+            zb, rb = (None if early else self._take(z, idx)), self._take(real, idx)
+            nb = rb.shape[0]
             chunk = self.generator_chunk if (self.generator_chunk and self.generator_chunk < nb) else None
             lane = real_logits = None
             if real_sum is None and self._overlap(n):
                 lane = K.fork()
                 with lane:
                     real_logits = D(rb).view(-1)
-            gen, tape_g = G.forward(zb, save=chunk is None)
+            if early:
+                gen, tape_g, early_gen, early_tape = early_gen, early_tape, None, None
+            else:
+                gen, tape_g = G.forward(zb, save=chunk is None)
             gen_logits, tape_d = D.forward(gen, save=True)
             del gen
             dgen = D.backward(tape_d, self._ones(nb), need_input_grad=True, need_weight_grads=False)

@@ -621,6 +621,33 @@ def test_real_pass_on_second_stream_changes_nothing(stage, fade, use_graph):
         assert np.array_equal(a, b)
 
 
+@pytest.mark.parametrize("stage,fade,use_graph", [(0, False, False), (1, True, True), (2, True, False)])
+def test_generator_forwards_ahead_on_third_stream_change_nothing(stage, fade, use_graph):
+    """WGAN.early_generator (default in the small-batch step): the generated batches of metric block 0 and of the
+    generator update are computed on a third stream beside the discriminator update.  The latent draws keep their
+    order and the generator is not touched by the discriminator update, so metrics and weights after 4 steps must
+    equal the in-order step bit for bit, eagerly and as a replayed graph."""
+    runs = []
+    for early in (False, True):
+        d, g, comp, _ = build(stage + 1)
+        gan = comp[stage][1 if fade else 0]
+        gan.seed(41)
+        gan.use_graph = use_graph
+        gan.early_generator = early
+        gan.set_train_steps(4)
+        metrics = []
+        for k in range(4):
+            real, _ = R.synthetic_inputs(stage, 8, seed=60 + k)
+            out = gan.train_step(real)
+            metrics.append({key: float(v) for key, v in out.items()})
+        weights = [v.numpy() for model in (gan.discriminator, gan.generator) for v in model.trainable_variables]
+        runs.append((metrics, weights))
+    (m_a, w_a), (m_b, w_b) = runs
+    assert m_a == m_b
+    for a, b in zip(w_a, w_b):
+        assert np.array_equal(a, b)
+
+
 @pytest.mark.parametrize("stage,fade,n,use_graph", [(0, False, 16, False), (1, True, 8, False), (2, True, 4, True),
                                                     (1, False, 2, False)])
 def test_merged_discriminator_passes_equal_separate_passes(stage, fade, n, use_graph):
