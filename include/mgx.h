@@ -364,6 +364,16 @@ int mgx_conv_pair_bf16_supported(int64_t nimg, int h, int w, int kb);
 int mgx_conv_pair_bf16(int64_t nimg, int h, int w, const void* x, const float* wa, const float* ba, float alpha_a,
                        const float* wb, const float* bb, float alpha_b, int kb, void* y, void* stream);
 
+/* The first two layers of a discriminator block (trainer/models.py:256-260) in one launch, for forward passes that
+ * keep no tape: Conv2D(128, 1x1) + SoftRectifier(alpha_a) on the float32 audio x (nimg, h, w, 2), then Conv2D(32,
+ * 3x3, 'same') + SoftRectifier(alpha_b); wa (2, 128), ba (128), wb (3, 3, 128, 32), bb (32) float32, y bf16
+ * (nimg, h, w, 32).  The 128-channel tensor between the two is re-computed per tile and never stored.  Results are
+ * bit-identical to mgx_pointwise2_bf16_fwd followed by mgx_conv_gemm_bf16.  Needs h a multiple of 16
+ * (mgx_audio_conv3_bf16_supported). */
+int mgx_audio_conv3_bf16_supported(int64_t nimg, int h, int w);
+int mgx_audio_conv3_bf16(int64_t nimg, int h, int w, const float* x, const float* wa, const float* ba, float alpha_a,
+                         const float* wb, const float* bb, float alpha_b, void* y, void* stream);
+
 /* A chain of two or three consecutive Conv2D(32, k x k, 'same') + SoftRectifier layers of a discriminator block
  * (trainer/models.py:259-276) in one launch, for forward passes that keep no tape.  ksizes = {3,3,2}, {3,3} or
  * {3,2} (mgx_conv_chain_bf16_supported); x and y are bf16 NHWC (nimg, h, w, 32); weights[i] / biases[i] the

@@ -121,6 +121,8 @@ PROTOTYPES = {
     "mgx_conv_gemm_bf16": (_I, [_DESC, _P, _P, _P, _P, _P, _P, _P]),
     "mgx_conv_pair_bf16_supported": (_I, [_I64, _I, _I, _I]),
     "mgx_conv_pair_bf16": (_I, [_I64, _I, _I, _P, _P, _P, _F, _P, _P, _F, _I, _P, _P]),
+    "mgx_audio_conv3_bf16_supported": (_I, [_I64, _I, _I]),
+    "mgx_audio_conv3_bf16": (_I, [_I64, _I, _I, _P, _P, _P, _F, _P, _P, _F, _P, _P]),
     "mgx_conv_chain_bf16_supported": (_I, [_I64, _I, _I, _I, _P]),
     "mgx_conv_chain_bf16": (_I, [_I64, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P]),
     "mgx_conv_wgrad_bf16_workspace": (_I64, [_DESC]),

@@ -401,6 +401,23 @@ class Model:
                 continue
             xs = [vals[id(t)] for t in op.inputs]
             if (not save and Model.use_conv_chains and not isinstance(op, _FusedOp) and op.act_node is not None
+                    and K.bf16_enabled() and xs[0].dtype == torch.float32 and i + 1 < len(plan)):
+                # the from-audio convolution and the 3x3 convolution behind it: the 128-channel tensor between
+                # them is re-computed per tile instead of stored (mgx_audio_conv3_bf16; bit-identical results)
+                nxt = plan[i + 1]
+                if (not isinstance(nxt, _FusedOp) and nxt.act_node is not None and len(nxt.inputs) == 1
+                        and nxt.inputs[0] is op.output and n_consumers.get(id(op.output), 0) == 1
+                        and op.output is not self.output):
+                    from .layers import audio_conv_eligible, audio_conv_forward
+                    if audio_conv_eligible(op.node.layer, nxt.node.layer, xs[0]):
+                        vals[id(nxt.output)] = audio_conv_forward(op.node.layer, op.act_node.layer.alpha_value,
+                                                                  nxt.node.layer, nxt.act_node.layer.alpha_value, xs[0])
+                        for t in op.inputs:
+                            if last_use.get(id(t)) == i and t is not self.output:
+                                vals.pop(id(t), None)
+                        skip = i + 1
+                        continue
+            if (not save and Model.use_conv_chains and not isinstance(op, _FusedOp) and op.act_node is not None
                     and K.bf16_enabled() and xs[0].dtype == torch.bfloat16):
                 chain = self._conv_chain(plan, i, n_consumers, xs[0])
                 if chain is not None:

@@ -207,6 +207,26 @@ def conv_pair_forward(a, alpha_a, b, alpha_b, x):
     return y
 
 
+def audio_conv_eligible(a, b, x) -> bool:
+    """Layers a, b (each followed by a SoftRectifier) as one launch of the from-audio + 3x3 kernel: a is the
+    Conv2D(128, 1x1) on the 2-channel float32 audio, b the Conv2D(32, 3x3, same) behind it; bf16 precision on."""
+    if not (K.bf16_enabled() and isinstance(a, Conv2D) and isinstance(b, Conv2D)):
+        return False
+    if x.dim() != 4 or x.dtype != torch.float32 or x.shape[-1] != 2 or x.shape[1] < K.BF16_MIN_ROWS:
+        return False
+    if a.cin != 2 or a.filters != 128 or a.kernel_size != (1, 1) or a.strides != (1, 1):
+        return False
+    if b.cin != 128 or b.filters != 32 or b.kernel_size != (3, 3) or b.padding != "same" or b.strides != (1, 1):
+        return False
+    return ops.audio_conv3_bf16_supported(x.shape[0], x.shape[1], x.shape[2])
+
+
+def audio_conv_forward(a, alpha_a, b, alpha_b, x):
+    y = K.empty(tuple(x.shape[:3]) + (32,), dtype=torch.bfloat16)
+    ops.audio_conv3_bf16(x, a.kernel.value(), a.bias.value(), alpha_a, b.kernel.value(), b.bias.value(), alpha_b, y)
+    return y
+
+
 def conv_chain_eligible(layers, x) -> bool:
     """Two or three layers (each followed by a SoftRectifier) as one launch of the chain kernel: Conv2D(32, k x k,
     same) on 32 channels with kernel sizes {3,3,2}, {3,3} or {3,2}, bf16 input, bf16 precision on."""

@@ -616,6 +616,26 @@ def conv_pair_bf16(x, wa, ba, alpha_a, wb, bb, alpha_b, kb, y):
         PROFILER.stop("bpair_kernel<%d>" % kb, 2.0 * (9 + kb * kb) * 1024 * px, e0, px * 128)
 
 
+def audio_conv3_bf16_supported(n, h, w) -> bool:
+    return bool(_lib().mgx_audio_conv3_bf16_supported(int(n), int(h), int(w)))
+
+
+def audio_conv3_bf16(x, wa, ba, alpha_a, wb, bb, alpha_b, y):
+    """mgx_audio_conv3_bf16: Conv2D(128, 1x1) + SoftRectifier on float32 audio (n, h, w, 2), then Conv2D(32, 3x3, same)
+    + SoftRectifier -> bf16 (n, h, w, 32), the 128-channel tensor between them never stored; no tape."""
+    n, h, w, c = x.shape
+    if c != 2 or x.dtype != torch.float32 or tuple(y.shape) != (n, h, w, 32) or y.dtype != torch.bfloat16:
+        raise MgxError("audio_conv3_bf16: x must be float32 (n, h, w, 2), y bf16 (n, h, w, 32)")
+    if wa.numel() != 256 or ba.numel() != 128 or wb.numel() != 9 * 128 * 32 or bb.numel() != 32:
+        raise MgxError("audio_conv3_bf16: kernels must be (1,1,2,128) and (3,3,128,32), biases (128,) and (32,)")
+    e0 = PROFILER.start() if PROFILER is not None else None
+    check(_lib().mgx_audio_conv3_bf16(n, h, w, _p(x), _p(wa), _p(ba), float(alpha_a), _p(wb), _p(bb), float(alpha_b),
+                                      _pb(y), K.stream_ptr()), "mgx_audio_conv3_bf16")
+    if e0 is not None:
+        px = n * h * w
+        PROFILER.stop("baudio_kernel", 2.0 * (9 * 128 * 32 + 2 * 128) * px, e0, px * (8 + 64))
+
+
 def conv_chain_bf16_supported(n, h, w, ksizes) -> bool:
     ks = (C.c_int * len(ksizes))(*[int(k) for k in ksizes])
     return bool(_lib().mgx_conv_chain_bf16_supported(int(n), int(h), int(w), len(ksizes), ks))

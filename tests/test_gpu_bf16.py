@@ -738,3 +738,35 @@ def test_bf16_weighted_sum_backward_applies_producer_derivatives():
         assert torch.equal(da1, want_a if use_a else da0)
         assert torch.equal(db1, want_b if use_b else db0)
         assert torch.equal(dal1, dal0)
+
+
+@pytest.mark.parametrize("h,w,n", [(16, 64, 1), (16, 31, 2), (32, 100, 3), (48, 333, 1), (64, 500, 2), (16, 8, 1)])
+def test_bf16_audio_conv_equals_separate_launches(h, w, n):
+    """mgx_audio_conv3_bf16 (from-audio 1x1 convolution + activation and the 3x3 convolution + activation behind it
+    in one launch, the 128-channel tensor re-computed per tile) against mgx_pointwise2_bf16_fwd followed by
+    mgx_conv_gemm_bf16: the same arithmetic on the same values in the same order, so the outputs must be equal bit
+    for bit, on ragged tiles, at the image borders (the convolution pads the ACTIVATION with zeros, not the audio)
+    and across images."""
+    M.clear_session()
+    a = L.Conv2D(128, (1, 1), padding="same", kernel_initializer="he_normal")
+    b = L.Conv2D(32, (3, 3), padding="same", kernel_initializer="he_normal")
+    a(Input(shape=(h, w, 2)))
+    b(Input(shape=(h, w, 128)))
+    rng = np.random.default_rng(h * 100 + w)
+    a.bias.assign(rng.uniform(-0.5, 0.5, (128,)).astype(np.float32))
+    b.bias.assign(rng.uniform(-0.3, 0.3, (32,)).astype(np.float32))
+    x = torch.from_numpy(rng.uniform(-1, 1, (n, h, w, 2)).astype(np.float32)).cuda()
+    alpha_a, alpha_b = 11000.0, 7.0
+    mid = torch.empty((n, h, w, 128), dtype=torch.bfloat16, device="cuda")
+    want = torch.empty((n, h, w, 32), dtype=torch.bfloat16, device="cuda")
+    ops.pointwise2_bf16_fwd(x, a.kernel.value(), a.bias.value(), mid, None, n * h * w, alpha_a)
+    ops.conv_gemm_bf16(b._desc("f", n, h, w), mid, b.kernel.value(), b.bias.value(), want, act_alpha=alpha_b)
+    assert ops.audio_conv3_bf16_supported(n, h, w)
+    assert not ops.audio_conv3_bf16_supported(n, 24, w) and not ops.audio_conv3_bf16_supported(n, 8, w)
+    got = torch.full_like(want, float("nan"))
+    ops.audio_conv3_bf16(x, a.kernel.value(), a.bias.value(), alpha_a, b.kernel.value(), b.bias.value(), alpha_b, got)
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(got.float()).all()), "positions left unwritten"
+    diff = (got.float() - want.float()).abs()
+    where = np.unravel_index(int(diff.argmax()), tuple(diff.shape))
+    assert torch.equal(got.view(torch.int16), want.view(torch.int16)), "max abs difference %.3e at %s" % (float(diff.max()), where)
