@@ -161,6 +161,33 @@ __global__ __launch_bounds__(256, KH * KW == 16 ? 1 : 2) void twgrad_kernel(mgx_
             if (dymul) stage_tile<RT, TW, true>(gl, dy, dymul, q.img, q.h0, q.w0, H, W, d.ngemm, nc * 32);
             else stage_tile<RT, TW, false>(gl, dy, dymul, q.img, q.h0, q.w0, H, W, d.ngemm, nc * 32);
             __syncthreads();
+            if constexpr (RT == 4 && KH > 1) {
+                // 4-row tiles: wave wv takes 8 columns of all four rows, and a tap row that lies in the padding
+                // above or below the image (zeros in the staged tile) is skipped - every wave skips the same ones
+                const int hb = q.h0 - d.pt;
+#pragma unroll
+                for (int row = 0; row < 4; ++row) {
+                    float bv[4];
+#pragma unroll
+                    for (int j = 0; j < 4; ++j) {
+                        bv[j] = gl[(row * TW + wv * 8 + j * 2 + h) * 32 + r];
+                        bsum[nc] += bv[j];
+                    }
+#pragma unroll
+                    for (int a = 0; a < KH; ++a) {
+                        if ((unsigned)(hb + row + a) < (unsigned)H) {
+#pragma unroll
+                            for (int j = 0; j < 4; ++j)
+#pragma unroll
+                                for (int b = 0; b < KW; ++b) {
+                                    const float av = xl[((row + a) * IW + (wv * 8 + j * 2 + h + b)) * 32 + r];
+                                    if constexpr (TAPS == 16) mfma_acc(acc[(a * KW + b) * NCH + nc], av, bv[j]);
+                                    else acc[(a * KW + b) * NCH + nc] = mfma32(av, bv[j], acc[(a * KW + b) * NCH + nc]);
+                                }
+                        }
+                    }
+                }
+            } else
 #pragma unroll 4
             for (int pp = 0; pp < RT * 4; ++pp) {
                 const int px = pp * 2 + h;               // within this wave's RT/4 rows

@@ -24,7 +24,8 @@ namespace {
 constexpr int PSTR = 36;
 // A tile is 256 output positions: TH = 8 rows x 32 columns (wave w owns row w) or, for images whose
 // height is a multiple of 4 only (the 4-row base block), TH = 4 rows x 64 columns (wave w owns row
-// w % 4, column half w / 4).
+// (w & 1) + 2 (w >> 2) of column half (w >> 1) & 1).  In an image of exactly 4 rows the tap rows that read
+// nothing but padding are skipped: 1 of 3 for the outer output rows of a 3x3 kernel, 4 of the 16 of a 4x4.
 
 // The 16 weight slices of a 4x4 kernel leave room for one input tile only: its next tile waits in
 // registers until every wave is done with the current one (one more barrier per tile).
@@ -178,7 +179,16 @@ __global__ __launch_bounds__(512, 2) void tconv3_kernel(mgx_conv_desc d, const f
     // past the row end are dropped by the hardware range check, the per-register part of the
     // offset is a scalar, so a store costs no vector ALU work.
     const int wvs = __builtin_amdgcn_readfirstlane(wv);
-    const int wrow = TH == 8 ? wvs : (wvs & 3), wcol = TH == 8 ? 0 : (wvs >> 2) * 32;     // the wave's row and first column in the tile
+    // the wave's row and first column in the tile.  On 4-row tiles the two waves of a SIMD (w and w + 4) take
+    // rows p and p + 2 of one column half: in an image of exactly 4 rows every output row has tap rows that
+    // fall into the padding (skipped below), and with this pairing each SIMD is left the same number of them.
+    const int wrow = TH == 8 ? wvs : ((wvs & 1) + 2 * (wvs >> 2)), wcol = TH == 8 ? 0 : ((wvs >> 1) & 1) * 32;
+    // tap rows [ta_lo, ta_hi) of this wave's output row read image rows; the others read zeros only
+    int ta_lo = 0, ta_hi = KH;
+    if (TH == 4 && H == 4 && gin_w == 0 && !scat) {
+        ta_lo = max(0, d.pt - wrow);
+        ta_hi = min(KH, 4 + d.pt - wrow);
+    }
     auto epilogue = [&](const f32x16& a, long t_, int oc_) {
         const int n = (nchunks > 1 ? oc_ : 0) * 32 + r;
         long img; int h0, w0;
@@ -262,14 +272,33 @@ __global__ __launch_bounds__(512, 2) void tconv3_kernel(mgx_conv_desc d, const f
                 aq[slot] = *(const f32x4*)(abase + (ta * IW + tb) * PSTR + 4 * j);
                 wq[slot] = *(const f32x4*)(wbase + tap * 1024 + j * 128);
             };
-            rd(0, 0);
-            rd(1, 1);
+            if (TH == 4 && KH > 1) {
+                // one software pipeline per tap row, so that a row of padding is skipped as a whole
+                constexpr int RQ = 4 * KW;
 #pragma unroll
-            for (int q = 0; q < NQ; ++q) {
-                if (q + 2 < NQ) rd(q + 2, (q + 2) % 3);
+                for (int ta = 0; ta < KH; ++ta) {
+                    if (ta >= ta_lo && ta < ta_hi) {
+                        rd(ta * RQ, 0);
+                        rd(ta * RQ + 1, 1);
 #pragma unroll
-                for (int s = 0; s < 4; ++s) acc = mfma32(aq[q % 3][s], wq[q % 3][s], acc);
-                __builtin_amdgcn_sched_barrier(0);
+                        for (int q = 0; q < RQ; ++q) {
+                            if (q + 2 < RQ) rd(ta * RQ + q + 2, (q + 2) % 3);
+#pragma unroll
+                            for (int s = 0; s < 4; ++s) acc = mfma32(aq[q % 3][s], wq[q % 3][s], acc);
+                            __builtin_amdgcn_sched_barrier(0);
+                        }
+                    }
+                }
+            } else {
+                rd(0, 0);
+                rd(1, 1);
+#pragma unroll
+                for (int q = 0; q < NQ; ++q) {
+                    if (q + 2 < NQ) rd(q + 2, (q + 2) % 3);
+#pragma unroll
+                    for (int s = 0; s < 4; ++s) acc = mfma32(aq[q % 3][s], wq[q % 3][s], acc);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
             }
         }
         if (S > 1 || NBUF == 1) __syncthreads();        // every wave is done with the weight slice (the input tile)
