@@ -72,6 +72,8 @@ def parse_args():
     ap.add_argument("--infer", action="store_true", help="generator-only inference line (BASELINE configs[4])")
     ap.add_argument("--clips", type=int, default=256, help="--infer: clips to generate in the timed region")
     ap.add_argument("--chunk", type=int, default=8, help="--infer: clips per generator call")
+    ap.add_argument("--collapsed", action="store_true",
+                    help="--infer: also time the opt-in collapsed generator (labelled, float32, chunks of 64)")
     ap.add_argument("--infer-stage", type=int, default=6)
     ap.add_argument("--graph", action="store_true",
                     help="replay the step as one HIP graph (WGAN.use_graph): for small batches, where the host's "
@@ -319,6 +321,42 @@ def infer_run(torch, M, ops, precision, stage, clips, chunk):
     return out
 
 
+def collapsed_infer_run(torch, M, ops, stage, clips, chunk):
+    """The labelled inference optimisation next to BASELINE configs[4] (not the reference's computation order and
+    no part of any MFMA figure): the generator's layers in front of its LayerNormalization are all linear, so
+    inference.CollapsedGenerator measures them once with five probe latents and then writes every clip directly.
+    Same sink and latents as infer_run; the table build is timed separately."""
+    from music_generator_amd.inference import ChecksumSink, CollapsedGenerator, generate_clips
+    M.backend.set_precision("float32")
+    M.clear_session()
+    torch.cuda.empty_cache()
+    g = M.define_generator(stage + 1)[stage][0]
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    cg = CollapsedGenerator(g)
+    torch.cuda.synchronize()
+    build_ms = (time.perf_counter() - t0) * 1e3
+    generate_clips(cg, chunk, chunk, ChecksumSink(), seed=1)
+    torch.cuda.synchronize()
+    sink = ChecksumSink()
+    t0 = time.perf_counter()
+    n = generate_clips(cg, clips, chunk, sink, seed=2)
+    torch.cuda.synchronize()
+    dt = time.perf_counter() - t0
+    chk = sink.result()
+    h, w = 4 << stage, 750 << stage
+    clip_bytes = h * w * 2 * 4
+    return {"value": round(n / dt, 1), "unit": "clips/s", "clips": n, "chunk": chunk,
+            "seconds_for_4096_clips": round(4096 * dt / n, 3), "table_build_ms": round(build_ms, 1),
+            "hbm_GBps_written_and_checksummed": round(2 * n * clip_bytes / dt / 1e9, 1),
+            "frac_of_8TBps": round(2 * n * clip_bytes / dt / 8e12, 3), "finite": bool(np_isfinite(chk)),
+            "clip_mean_square_range": [float(chk[:, 1].min() / (h * w * 2)), float(chk[:, 1].max() / (h * w * 2))],
+            "note": "opt-in algebraic collapse of the all-linear generator (inference.CollapsedGenerator, float32): "
+                    "each clip is written once from a 5-vector table and read once by the checksum sink; equals the "
+                    "layer path to float32 rounding (tests/test_gpu_inference.py); not the reference's computation "
+                    "order, no MFMA work, not the c5 headline"}
+
+
 def np_isfinite(a):
     import numpy as np
     return np.isfinite(a).all()
@@ -342,7 +380,10 @@ def main():
         if world > 1:
             raise SystemExit("--infer is a single-GPU line (clips are independent: run one process per GPU)")
         torch.cuda.set_device(0)
-        print(json.dumps(infer_run(torch, M, ops, args.precision, args.infer_stage, args.clips, args.chunk)))
+        r = infer_run(torch, M, ops, args.precision, args.infer_stage, args.clips, args.chunk)
+        if args.collapsed:
+            r["collapsed_f32"] = collapsed_infer_run(torch, M, ops, args.infer_stage, max(args.clips, 64), 64)
+        print(json.dumps(r))
         return
 
     # one rank per GPU; MGX_BENCH_BACKEND=gloo rehearses the multi-rank flow on a box with fewer GPUs
@@ -463,6 +504,8 @@ def main():
                                       "hbm_ops", "peak_hbm_gib", "finite")}
                 out["c5"]["workload"] = r["config"]["workload"]
                 progress("c5 %s: %.1f clips/s" % (precision, r["value"]))
+            out["c5"]["collapsed_f32"] = collapsed_infer_run(torch, M, ops, 6, 1024, 64)
+            progress("c5 collapsed: %.0f clips/s" % out["c5"]["collapsed_f32"]["value"])
         if not args.no_cpu_baseline:
             progress("CPU baseline")
             out["cpu_baseline"] = cpu_baseline(stage, fade, args.cpu_sample_batch, n_blocks)

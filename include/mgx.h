@@ -212,6 +212,19 @@ int mgx_add_inplace(float* dst, const float* src, int64_t n, void* stream);
  * reference; it is what lets the upper stages fit in HBM. */
 int mgx_gather_groups(const float* src, float* dst, int64_t row_floats, int g, int m, int m0, int cnt, void* stream);
 
+/* Generator inference through the collapsed affine map - an opt-in inference path with no counterpart in the
+ * reference, whose generator (models.py:358-399, 412-450) has no non-linearity in front of its final
+ * LayerNormalization: the tensor entering the normalisation is T[p][ch][0] + sum_k z[c][k] T[p][ch][1+k] for latent
+ * column pair c (the 4 numbers z[0, 2c..2c+1, :]) and position p = (row, j) of the h x wp patch the pair produces.
+ * mgx_collapse_table builds T ((h*wp) x 2 x 5 floats) from `probe` = that tensor for five latents (zero, then the
+ * four unit vectors set at every column pair; 5 x h x (ncols*wp) x 2 floats) and `gram` (20 doubles: sums and
+ * products of the five table vectors).  mgx_collapse_apply writes out[n] = gamma * (pre[n] - mean_n) * rstd_n + beta
+ * (nclips x h x (ncols*wp) x 2 floats) for latents z (nclips x ncols x 4 floats); mean and rstd = 1/sqrt(var + eps)
+ * come from `gram` (no pass over the clip) and are left in stats (nclips x 2 floats). */
+int mgx_collapse_table(const float* probe, float* table, double* gram, int h, int wp, int ncols, void* stream);
+int mgx_collapse_apply(const float* table, const double* gram, const float* z, const float* gamma, const float* beta,
+                       float* out, float* stats, int nclips, int h, int wp, int ncols, float eps, void* stream);
+
 /* WeightedSum (models.py:30-35): y = (1-alpha)*a + alpha*b, alpha read from device memory.
  * Backward: da (+)= (1-alpha)*dy, db (+)= alpha*dy, dalpha += sum(dy*(b-a)) (if dalpha != NULL;
  * workspace of mgx_reduce_workspace() bytes). da/db may be NULL. */

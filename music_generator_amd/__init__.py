@@ -5,7 +5,7 @@ include/mgx.h) through ops.py."""
 from . import backend  # noqa: F401
 from .backend import clear_session  # noqa: F401
 from .graph import Input, Model  # noqa: F401
-from .inference import ChecksumSink, HostRingSink, draw_latents, generate_clips  # noqa: F401
+from .inference import ChecksumSink, CollapsedGenerator, HostRingSink, draw_latents, generate_clips  # noqa: F401
 from .models import (Adam, GANMonitor, MinibatchStdDev, SoftRectifier, StaticOptTanh, WGAN, WeightedSum,  # noqa: F401
                      add_discriminator_block, add_generator_block, define_composite, define_discriminator,
                      define_generator, discriminator_loss, generator_loss)
@@ -13,4 +13,4 @@ from .models import (Adam, GANMonitor, MinibatchStdDev, SoftRectifier, StaticOpt
 __all__ = ["backend", "clear_session", "Input", "Model", "Adam", "GANMonitor", "MinibatchStdDev", "SoftRectifier",
            "StaticOptTanh", "WGAN", "WeightedSum", "add_discriminator_block", "add_generator_block",
            "define_composite", "define_discriminator", "define_generator", "discriminator_loss", "generator_loss",
-           "generate_clips", "draw_latents", "ChecksumSink", "HostRingSink"]
+           "generate_clips", "draw_latents", "ChecksumSink", "HostRingSink", "CollapsedGenerator"]

@@ -94,6 +94,8 @@ PROTOTYPES = {
     "mgx_add_n": (_I, [C.POINTER(_P), _I, _P, _I64, _P]),
     "mgx_add_inplace": (_I, [_P, _P, _I64, _P]),
     "mgx_gather_groups": (_I, [_P, _P, _I64, _I, _I, _I, _I, _P]),
+    "mgx_collapse_table": (_I, [_P, _P, _P, _I, _I, _I, _P]),
+    "mgx_collapse_apply": (_I, [_P, _P, _P, _P, _P, _P, _P, _I, _I, _I, _I, _F, _P]),
     "mgx_weighted_sum_fwd": (_I, [_P, _P, _P, _P, _I64, _P]),
     "mgx_weighted_sum_bwd": (_I, [_P, _P, _P, _P, _P, _I, _P, _I, _P, _P, _I64, _I64, _P]),
     "mgx_reduce_workspace": (_I64, []),

@@ -394,6 +394,34 @@ def gather_groups(src, g, m, m0, cnt):
     return dst
 
 
+def collapse_table(probe, ncols):
+    """mgx_collapse_table: (table, gram) of the collapsed generator from the probe tensor (5, H, ncols * wp, 2)."""
+    if probe.dtype != torch.float32 or probe.dim() != 4 or probe.shape[0] != 5 or probe.shape[3] != 2 \
+            or probe.shape[2] % ncols or not probe.is_contiguous():
+        raise MgxError("collapse_table: a contiguous float32 probe of shape (5, H, ncols * wp, 2) is expected")
+    h, wp = int(probe.shape[1]), int(probe.shape[2]) // int(ncols)
+    table = K.empty((h * wp, 2, 5))
+    gram = K.empty((20,), dtype=torch.float64)
+    check(_lib().mgx_collapse_table(_p(probe), _p(table), gram.data_ptr(), h, wp, int(ncols), K.stream_ptr()),
+          "mgx_collapse_table")
+    return table, gram
+
+
+def collapse_apply(table, gram, z, gamma, beta, h, wp, ncols, eps):
+    """mgx_collapse_apply: normalised clips (n, h, ncols * wp, 2) of the latents z (n, ncols * 4 numbers)."""
+    n = int(z.shape[0])
+    if z.dtype != torch.float32 or not z.is_contiguous() or z.numel() != n * ncols * 4:
+        raise MgxError("collapse_apply: latents must be contiguous float32, ncols * 4 numbers a clip")
+    if table.numel() != h * wp * 10 or gram.numel() != 20 or gram.dtype != torch.float64 or gamma.numel() != h * wp * ncols * 2 \
+            or beta.numel() != gamma.numel():
+        raise MgxError("collapse_apply: table / gamma / beta do not match h, wp, ncols")
+    out = K.empty((n, h, ncols * wp, 2))
+    stats = K.empty((n, 2))
+    check(_lib().mgx_collapse_apply(_p(table), gram.data_ptr(), _p(z), _p(gamma), _p(beta), _p(out), _p(stats), n, int(h),
+                                    int(wp), int(ncols), float(eps), K.stream_ptr()), "mgx_collapse_apply")
+    return out
+
+
 def add_inplace(dst, src):
     if dst.numel() != src.numel():
         raise MgxError("add_inplace: size mismatch")

@@ -116,3 +116,61 @@ def test_bf16_inference_close_to_float32():
             M.backend.set_precision("float32")
     err = rel_l2(out["bfloat16"], out["float32"])
     assert err < 5e-2, err
+
+
+@pytest.mark.parametrize("stage,fade", [(0, False), (1, True), (2, False), (2, True)])
+def test_collapsed_generator_equals_layer_path(stage, fade):
+    """The opt-in collapsed inference path (one table lookup + normalisation per output value) against the
+    layer kernels and against the float64 oracle on the same latents.  Both float32 evaluations are within 1e-4
+    (max abs, post-normalisation values are O(1)) of the oracle; against each other 5e-5."""
+    from music_generator_amd.inference import CollapsedGenerator
+    d, g, comp, W = build(stage + 1)
+    names = R.layer_names(stage + 1)
+    model = g[stage][1 if fade else 0]
+    alpha = 0.37 if fade else None
+    Wt = {k: torch.tensor(v, dtype=torch.float64) for k, v in W.items()}
+    if fade:
+        for layer in model.layers:
+            if isinstance(layer, M.WeightedSum):
+                M.backend.set_value(layer.alpha, alpha)
+        Wt[names["g"][stage]["ws"] + "/alpha"] = torch.tensor(alpha, dtype=torch.float64)
+    n = 6
+    z = np.random.default_rng(11).standard_normal((n, 1, 100, 2)).astype(np.float32)
+    zt = torch.tensor(z, device="cuda")
+    layers = model(zt, training=False).cpu().numpy()
+    cg = CollapsedGenerator(model)
+    got = cg(zt).cpu().numpy()
+    want = R.generator(Wt, names, stage, fade, torch.tensor(z, dtype=torch.float64), alpha).numpy()
+    assert got.shape == layers.shape == want.shape
+    assert np.abs(got - want).max() < 1e-4
+    assert np.abs(got - layers).max() < 5e-5
+    # after a weight change the table is stale until refresh()
+    cg.norm.beta.assign(cg.norm.beta.numpy() + 0.5)
+    assert np.abs(cg(zt).cpu().numpy() - (got + 0.5)).max() < 1e-5      # beta is read at call time
+    first = model.layers[1]
+    first.kernel.assign(first.kernel.numpy() * 1.5)
+    cg.refresh()
+    assert np.abs(cg(zt).cpu().numpy() - model(zt, training=False).cpu().numpy()).max() < 5e-5
+
+
+def test_generate_clips_collapsed_sink_order_and_full_resolution():
+    """generate_clips(collapse=True): same chunking contract; at the full-resolution stage (256 x 48000) two
+    clips equal the layer path (relative L2 below 1e-5) and are normalised (mean 0, variance 1 - eps effect below 1e-3,
+    gamma = 1 and beta = 0 at initialisation)."""
+    M.clear_session()
+    g = M.define_generator(7)
+    model = g[6][0]
+    z = draw_latents(2, seed=5)
+    got = []
+    assert generate_clips(model, 2, 1, lambda first, a: got.append((first, a.clone())), z=z, collapse=True) == 2
+    assert [f for f, _ in got] == [0, 1]
+    audio = torch.cat([a for _, a in got])
+    assert tuple(audio.shape) == (2, 256, 48000, 2)
+    ref = model(z, training=False)
+    # 7 blocks of random linear maps give heavy-tailed values (|x| up to ~130 here; the largest difference
+    # measured is 2.8e-4): max abs <= 5e-6 max|x|
+    assert float((audio - ref).abs().max()) <= 5e-6 * float(ref.abs().max())
+    assert float((audio - ref).double().norm() / ref.double().norm()) < 1e-5
+    flat = audio.reshape(2, -1).double()
+    assert float(flat.mean(1).abs().max()) < 1e-4
+    assert float((flat.var(1, unbiased=False) - 1.0).abs().max()) < 2e-3

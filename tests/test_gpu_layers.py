@@ -53,6 +53,8 @@ CONV_CASES = [
     (4, 750, 32, 32, (4, 4), (1, 1), "same", 3),      # 4x4 tile kernel: 12 column tiles of 64, ragged last one
     (8, 130, 32, 32, (4, 4), (1, 1), "same", 2),      # 4x4 tile kernel over two tile rows of 4
     (8, 50, 32, 32, (3, 3), (1, 1), "same", 2),
+    (4, 130, 32, 32, (3, 3), (1, 1), "same", 2),      # 4-row tiles over an image of 4 rows: padding tap rows skipped
+    (12, 70, 32, 32, (3, 3), (1, 1), "same", 2),      # 4-row tiles over three tile rows: nothing to skip inside
     (16, 70, 128, 32, (3, 3), (1, 1), "same", 2),     # LDS-tiled path, 4 input-channel chunks
     (8, 33, 32, 32, (3, 3), (1, 1), "same", 3),       # LDS-tiled path, ragged right edge
     (12, 45, 64, 32, (3, 3), (1, 1), "same", 2),      # Winograd kernel: 4 channel steps, partial second tile row
