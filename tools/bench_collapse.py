@@ -1,3 +1,5 @@
+"""The collapsed generator (inference.CollapsedGenerator) at the full-resolution stage: difference to the layer
+path on two clips, then clips/s and write rate for chunks of 8, 32 and 64.  PYTHONPATH=. python tools/bench_collapse.py"""
 import torch, music_generator_amd as M
 from music_generator_amd.inference import CollapsedGenerator, draw_latents
 import time
