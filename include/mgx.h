@@ -358,6 +358,17 @@ int mgx_conv_bf16_supported(const mgx_conv_desc* d);
  * d->accumulate must be 0. */
 int mgx_conv_gemm_bf16(const mgx_conv_desc* d, const void* x, const float* w, const float* bias, void* y,
                        void* dact, const void* ymul, void* stream);
+/* The 1x1 convolution + SoftRectifier that ends a discriminator block (models.py:280-281) and the WeightedSum
+ * behind it (models.py:297, 30-35) in one launch, for passes that keep no tape: y = (1 - alpha) old + alpha
+ * act(conv(x) + bias); x, old, y bf16 (old of y's shape), alpha one float in device memory, act_alpha in the
+ * descriptor.  Rounded where the two launches it replaces round (results are bit-identical to them). */
+int mgx_conv1x1_blend_bf16(const mgx_conv_desc* d, const void* x, const float* w, const float* bias, const void* old,
+                           const float* alpha, void* y, void* stream);
+/* The same for float32 tensors (the 1x1 tile kernel, 32 -> 128 channels): mgx_conv1x1_blend_supported tells whether
+ * the descriptor is served. */
+int mgx_conv1x1_blend_supported(const mgx_conv_desc* d);
+int mgx_conv1x1_blend_f32(const mgx_conv_desc* d, const float* x, const float* w, const float* bias, const float* old,
+                          const float* alpha, float* y, void* stream);
 
 /* Weight / bias gradient for a forward descriptor mgx_conv_bf16_supported accepts: x the layer input,
  * g the gradient with respect to the pre-activation (both bf16); dw (Keras layout through the

@@ -121,6 +121,9 @@ PROTOTYPES = {
     "mgx_adam_multi_devlr": (_I, [_P, _P, _P, _P, _P, _P, _P, _I64, _P, _F, _F, _P]),
     "mgx_conv_bf16_supported": (_I, [_DESC]),
     "mgx_conv_gemm_bf16": (_I, [_DESC, _P, _P, _P, _P, _P, _P, _P]),
+    "mgx_conv1x1_blend_bf16": (_I, [_DESC, _P, _P, _P, _P, _P, _P, _P]),
+    "mgx_conv1x1_blend_supported": (_I, [_DESC]),
+    "mgx_conv1x1_blend_f32": (_I, [_DESC, _P, _P, _P, _P, _P, _P, _P]),
     "mgx_conv_pair_bf16_supported": (_I, [_I64, _I, _I, _I]),
     "mgx_conv_pair_bf16": (_I, [_I64, _I, _I, _P, _P, _P, _F, _P, _P, _F, _I, _P, _P]),
     "mgx_audio_conv3_bf16_supported": (_I, [_I64, _I, _I]),

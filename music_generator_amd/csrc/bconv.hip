@@ -20,7 +20,9 @@
 // offsets; columns past the row end are dropped by the store's range check.
 // Epilogues: bias + tanh(x)+x/alpha (+ optional store of the derivative for the backward pass);
 // multiply by a bf16 tensor of the output's shape (the data-gradient of a convolution whose input came
-// out of an activation: dY (.) f'); or plain.
+// out of an activation: dY (.) f'); plain; or (1x1 kernels, passes that keep no tape) bias + activation followed by
+// the fade-in blend (1 - alpha) old + alpha y of trainer/models.py:30-35 with a bf16 tensor `old` of the output's
+// shape, in place of a WeightedSum launch that would read the activation back.
 #include <cstdlib>
 #include "bf16.h"
 #include "../../include/mgx.h"
@@ -41,7 +43,10 @@ __global__ __launch_bounds__(64 * TH) void bconv_kernel(mgx_conv_desc d, const b
                                                        const float* __restrict__ w, const float* __restrict__ bias,
                                                        bf16_t* __restrict__ y, bf16_t* __restrict__ dact,
                                                        const bf16_t* __restrict__ ymul, long ntiles, int tiles_h,
-                                                       int tiles_w, int gin_w, int scat) {
+                                                       int tiles_w, int gin_w, int scat,
+                                                       const float* __restrict__ blend_alpha) {
+    // EPI: 0 plain, 1 bias + activation (+ derivative), 2 multiply by ymul, 3 = 1 followed by the blend with ymul
+    constexpr bool ACT = EPI == 1 || EPI == 3, PRE = EPI == 2 || EPI == 3;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     constexpr int TW = NT * 32, NTHR = 64 * TH;
     constexpr int IH = TH + KH - 1, IW = TW + KW - 1, TAPS = KH * KW, NPIX = IH * IW;
@@ -127,7 +132,7 @@ __global__ __launch_bounds__(64 * TH) void bconv_kernel(mgx_conv_desc d, const b
 
     // biases in LDS: an accumulation starts from the bias of its output channels instead of from zero
     float* bl = (float*)(xt + 2 * NPIX * 64);
-    if (EPI == 1)
+    if (ACT)
         for (int i = tid; i < N; i += NTHR) bl[i] = d.nbias > 0 ? bias[i] : 0.f;
 
     long t = blockIdx.x;
@@ -146,7 +151,7 @@ __global__ __launch_bounds__(64 * TH) void bconv_kernel(mgx_conv_desc d, const b
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             f32x4 v = (f32x4){0.f, 0.f, 0.f, 0.f};
-            if (EPI == 1) v = *(const f32x4*)(bl + nc_ * 32 + 8 * g + 4 * h);
+            if (ACT) v = *(const f32x4*)(bl + nc_ * 32 + 8 * g + 4 * h);
 #pragma unroll
             for (int nt = 0; nt < NT; ++nt)
 #pragma unroll
@@ -169,7 +174,7 @@ __global__ __launch_bounds__(64 * TH) void bconv_kernel(mgx_conv_desc d, const b
         coff = scat ? (nc_ & 1) * 64 + 16 * h : nc_ * 64 + 16 * h;    // the lane's first 16 bytes; the second 32 further
     };
     auto epilogue_prefetch = [&](long t_, int nc_) {
-        if (EPI == 2) {
+        if (PRE) {
             long rowoff; unsigned row_bytes; int pstride, coff, w0;
             epilogue_addr(t_, nc_, rowoff, row_bytes, pstride, coff, w0);
             const __amdgpu_buffer_rsrc_t rm =
@@ -194,7 +199,7 @@ __global__ __launch_bounds__(64 * TH) void bconv_kernel(mgx_conv_desc d, const b
             acc_rows_interleaved(a);
             const unsigned voff = (unsigned)((w0 + nt * 32 + r) * pstride + coff);
             unsigned o[8], dd[8];
-            if (EPI == 1) {
+            if (ACT) {
                 if (d.act_alpha > 0.f) {
 #pragma unroll
                     for (int i = 0; i < 16; i += 2) {
@@ -207,6 +212,16 @@ __global__ __launch_bounds__(64 * TH) void bconv_kernel(mgx_conv_desc d, const b
                 } else {
 #pragma unroll
                     for (int i = 0; i < 16; i += 2) o[i >> 1] = bf_pack(a[i], a[i + 1]);
+                }
+                if (EPI == 3) {
+                    const float al = blend_alpha[0], om = 1.0f - al;
+                    const u32x4 m0 = pre_m[nt][0], m1 = pre_m[nt][1];
+#pragma unroll
+                    for (int i = 0; i < 4; ++i) {
+                        o[i] = bf_pack(mgx_blend(om, bf_lo(m0[i]), al, bf_lo(o[i])), mgx_blend(om, bf_hi(m0[i]), al, bf_hi(o[i])));
+                        o[4 + i] = bf_pack(mgx_blend(om, bf_lo(m1[i]), al, bf_lo(o[4 + i])),
+                                           mgx_blend(om, bf_hi(m1[i]), al, bf_hi(o[4 + i])));
+                    }
                 }
             } else if (EPI == 2) {
                 const u32x4 m0 = pre_m[nt][0], m1 = pre_m[nt][1];
@@ -240,7 +255,7 @@ __global__ __launch_bounds__(64 * TH) void bconv_kernel(mgx_conv_desc d, const b
         const bool need_x = has_next && (kchunks > 1 || ocn == 0);
         if (need_x) stage_load(tn, kchunks > 1 ? ocn : 0);
         const bool ep_now = kchunks == 1 || oc == S - 1;
-        if (ep_now && EPI == 2) epilogue_prefetch(t, nchunks > 1 ? oc : 0);
+        if (ep_now && PRE) epilogue_prefetch(t, nchunks > 1 ? oc : 0);
         const unsigned char* xb = xt + cur * (NPIX * 64);
         const int kc = kchunks > 1 ? oc : 0, nc = nchunks > 1 ? oc : 0;
         const unsigned char* wb = wl + ((nc * TAPS * (K >> 4) + kc * 2) * 64 + lane) * 16;
@@ -270,7 +285,7 @@ __global__ __launch_bounds__(64 * TH) void bconv_kernel(mgx_conv_desc d, const b
 
 template <int KH, int KW, int TH, int NT>
 int launch_shape(const mgx_conv_desc& d, const bf16_t* x, const float* w, const float* bias, bf16_t* y, bf16_t* dact,
-                 const bf16_t* ymul, hipStream_t st, int gin_w, int scat) {
+                 const bf16_t* ymul, hipStream_t st, int gin_w, int scat, const float* blend_alpha = nullptr) {
     constexpr int TW = NT * 32;
     const int tiles_h = (d.hin + TH - 1) / TH, tiles_w = (d.win + TW - 1) / TW;
     const long ntiles = (long)d.nimg * tiles_h * tiles_w;
@@ -278,16 +293,19 @@ int launch_shape(const mgx_conv_desc& d, const bf16_t* x, const float* w, const 
     const unsigned grid = (unsigned)(ntiles < 256 ? ntiles : 256);
     const int lds = KH * KW * d.cin * d.ngemm * 2 + 2 * npix<KH, KW, TH, NT>() * 64 + d.ngemm * 4;
     if (lds > 160 * 1024) return MGX_ERR_ARG;
-    const int epi = ymul != nullptr ? 2 : ((d.nbias > 0 || d.act_alpha > 0.f) ? 1 : 0);
+    const int epi = blend_alpha != nullptr ? 3 : (ymul != nullptr ? 2 : ((d.nbias > 0 || d.act_alpha > 0.f) ? 1 : 0));
 #define MGX_B(E)                                                                                                     \
     do {                                                                                                             \
         if (hipFuncSetAttribute((const void*)bconv_kernel<KH, KW, E, TH, NT>,                                        \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)                      \
             return MGX_ERR_LAUNCH;                                                                                   \
         hipLaunchKernelGGL((bconv_kernel<KH, KW, E, TH, NT>), dim3(grid), dim3(64 * TH), lds, st, d, x, w, bias, y,  \
-                           dact, ymul, ntiles, tiles_h, tiles_w, gin_w, scat);                                       \
+                           dact, ymul, ntiles, tiles_h, tiles_w, gin_w, scat, blend_alpha);                          \
     } while (0)
-    if (epi == 2) MGX_B(2);
+    if (epi == 3) {
+        if constexpr (KH == 1 && KW == 1) MGX_B(3);
+        else return MGX_ERR_ARG;
+    } else if (epi == 2) MGX_B(2);
     else if (epi == 1) MGX_B(1);
     else MGX_B(0);
 #undef MGX_B
@@ -298,12 +316,12 @@ int launch_shape(const mgx_conv_desc& d, const bf16_t* x, const float* w, const 
 // weights; 8 x 64 tiles otherwise.  MGX_BCONV_TILE=8 / 16 forces a shape (measurements).
 template <int KH, int KW>
 int launch_b(const mgx_conv_desc& d, const bf16_t* x, const float* w, const float* bias, bf16_t* y, bf16_t* dact,
-             const bf16_t* ymul, hipStream_t st, int gin_w, int scat) {
+             const bf16_t* ymul, hipStream_t st, int gin_w, int scat, const float* blend_alpha = nullptr) {
     const int lds16 = KH * KW * d.cin * d.ngemm * 2 + 2 * npix<KH, KW, 16, 1>() * 64 + d.ngemm * 4;
     bool tall = d.hin >= 16 && d.hin % 16 == 0 && lds16 <= 160 * 1024;
     if (const char* e = getenv("MGX_BCONV_TILE")) tall = e[0] == '1' && lds16 <= 160 * 1024;
-    if (tall) return launch_shape<KH, KW, 16, 1>(d, x, w, bias, y, dact, ymul, st, gin_w, scat);
-    return launch_shape<KH, KW, 8, 2>(d, x, w, bias, y, dact, ymul, st, gin_w, scat);
+    if (tall) return launch_shape<KH, KW, 16, 1>(d, x, w, bias, y, dact, ymul, st, gin_w, scat, blend_alpha);
+    return launch_shape<KH, KW, 8, 2>(d, x, w, bias, y, dact, ymul, st, gin_w, scat, blend_alpha);
 }
 
 }  // namespace
@@ -348,4 +366,16 @@ extern "C" int mgx_conv_gemm_bf16(const mgx_conv_desc* dp, const void* x, const 
     if (d.kh == 3) return launch_b<3, 3>(d, xb, w, bias, yb, db, mb, st, 0, 0);
     if (d.kh == 2) return launch_b<2, 2>(d, xb, w, bias, yb, db, mb, st, 0, 0);
     return launch_b<1, 1>(d, xb, w, bias, yb, db, mb, st, 0, 0);
+}
+
+// The 1x1 convolution + SoftRectifier that ends a discriminator block (trainer/models.py:280-281) and the
+// WeightedSum behind it (models.py:297) in one launch, for passes that keep no tape:
+// y = (1 - alpha) old + alpha act(conv(x)), every intermediate rounded to bf16 where the two launches round it.
+extern "C" int mgx_conv1x1_blend_bf16(const mgx_conv_desc* dp, const void* x, const float* w, const float* bias,
+                                      const void* old, const float* alpha, void* y, void* stream) {
+    if (!dp || !x || !w || !old || !alpha || !y || !mgx_conv_bf16_supported(dp)) return MGX_ERR_ARG;
+    if (dp->kh != 1 || dp->kw != 1 || dp->sh != 1 || dp->dkh != 1 || dp->accumulate) return MGX_ERR_ARG;
+    if (dp->nbias > 0 && (!bias || dp->nbias != dp->ngemm)) return MGX_ERR_ARG;
+    return launch_b<1, 1>(*dp, (const bf16_t*)x, w, bias, (bf16_t*)y, nullptr, (const bf16_t*)old, (hipStream_t)stream, 0, 0,
+                          alpha);
 }

@@ -199,7 +199,7 @@ __global__ __launch_bounds__(kBlock) void wsum_b_fwd_kernel(const bf16_t* __rest
         u32x4 o;
 #pragma unroll
         for (int k = 0; k < 4; ++k)
-            o[k] = bf_pack(om * bf_lo(av[k]) + al * bf_lo(bv[k]), om * bf_hi(av[k]) + al * bf_hi(bv[k]));
+            o[k] = bf_pack(mgx_blend(om, bf_lo(av[k]), al, bf_lo(bv[k])), mgx_blend(om, bf_hi(av[k]), al, bf_hi(bv[k])));
         ((u32x4*)y)[i] = o;
     }
 }

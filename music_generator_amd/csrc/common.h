@@ -71,6 +71,12 @@ __device__ __forceinline__ void tanh_sech2(float x, float& t, float& s) {
     s = 4.0f * e * inv * inv;
 }
 
+// WeightedSum of trainer/models.py:30-35 for one element, (1 - alpha) a + alpha b with om = 1 - alpha: one
+// rounding order for the blend kernels and for the convolution epilogues that blend in place of a launch.
+__device__ __forceinline__ float mgx_blend(float om, float a, float al, float b) {
+    return __builtin_fmaf(om, a, al * b);
+}
+
 static inline int mgx_launch_status() {
     return hipGetLastError() == hipSuccess ? MGX_OK : MGX_ERR_LAUNCH;
 }

@@ -145,10 +145,11 @@ __global__ __launch_bounds__(kBlock) void wsum_fwd_kernel(const float* __restric
     const float al = alpha[0], om = 1.0f - al;
     for (long i = (long)blockIdx.x * kBlock + threadIdx.x; i < n4; i += (long)gridDim.x * kBlock) {
         const float4 u = ((const float4*)a)[i], v = ((const float4*)b)[i];
-        ((float4*)y)[i] = make_float4(om * u.x + al * v.x, om * u.y + al * v.y, om * u.z + al * v.z, om * u.w + al * v.w);
+        ((float4*)y)[i] = make_float4(mgx_blend(om, u.x, al, v.x), mgx_blend(om, u.y, al, v.y), mgx_blend(om, u.z, al, v.z),
+                                      mgx_blend(om, u.w, al, v.w));
     }
     const long t = n4 * 4 + (long)blockIdx.x * kBlock + threadIdx.x;
-    if (t < n) y[t] = om * a[t] + al * b[t];
+    if (t < n) y[t] = mgx_blend(om, a[t], al, b[t]);
 }
 
 // da (+)= (1-alpha) dy ; db (+)= alpha dy ; block partial of sum dy*(b-a) -> part[blockIdx.x]

@@ -295,11 +295,25 @@ bool mgx_tconv_applicable(const mgx_conv_desc& d) {
 }
 
 int mgx_tconv3_launch(const mgx_conv_desc& d, const float* x, const float* xmul, const float* w, const float* bias,
-                      float* y, float* dact, hipStream_t st);
+                      float* y, float* dact, hipStream_t st, const float* blend_old, const float* blend_alpha);
 
 int mgx_tconv_launch(const mgx_conv_desc& d, const float* x, const float* xmul, const float* w, const float* bias,
                      float* y, float* dact, hipStream_t st) {
-    return mgx_tconv3_launch(d, x, xmul, w, bias, y, dact, st);   // tconv3.hip
+    return mgx_tconv3_launch(d, x, xmul, w, bias, y, dact, st, nullptr, nullptr);   // tconv3.hip
+}
+
+// The 1x1 convolution + SoftRectifier that ends a discriminator block (trainer/models.py:280-281) and the
+// WeightedSum behind it (models.py:297) in one launch, for passes that keep no tape.
+extern "C" int mgx_conv1x1_blend_supported(const mgx_conv_desc* d) {
+    return d && d->kh == 1 && d->kw == 1 && d->sh == 1 && d->sw == 1 && d->dkh == 1 && d->dkw == 1 && !d->accumulate &&
+           d->cin == 32 && d->ngemm == 128 && mgx_tconv_applicable(*d);
+}
+
+extern "C" int mgx_conv1x1_blend_f32(const mgx_conv_desc* d, const float* x, const float* w, const float* bias,
+                                     const float* old, const float* alpha, float* y, void* stream) {
+    if (!d || !x || !w || !old || !alpha || !y || !mgx_conv1x1_blend_supported(d)) return MGX_ERR_ARG;
+    if (d->nbias > 0 && (!bias || d->nbias != d->ngemm)) return MGX_ERR_ARG;
+    return mgx_tconv3_launch(*d, x, nullptr, w, bias, y, nullptr, (hipStream_t)stream, old, alpha);
 }
 
 // weight gradient: same applicability on the FORWARD descriptor; 32 output channels, or the 1x1

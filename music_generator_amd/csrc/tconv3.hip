@@ -43,7 +43,11 @@ __global__ __launch_bounds__(512, 2) void tconv3_kernel(mgx_conv_desc d, const f
                                                         const float* __restrict__ w,
                                                         const float* __restrict__ bias, float* __restrict__ y,
                                                         float* __restrict__ dact, long ntiles, int tiles_h,
-                                                        int tiles_w, int gin_w, int scat) {
+                                                        int tiles_w, int gin_w, int scat,
+                                                        const float* __restrict__ blend_old,
+                                                        const float* __restrict__ blend_alpha) {
+    // blend_alpha != nullptr (1x1 kernels, passes that keep no tape): the output is the fade-in blend
+    // (1 - alpha) blend_old + alpha y of trainer/models.py:30-35 instead of y, blend_old of the output's shape.
     // gin_w > 0 (1x1 kernels only): the 128 input channels of position (i, j) are the 2x2 window at
     // (2i, 2j) of a 32-channel image gin_w columns wide, slice kc = tap (kc / 2, kc % 2): a 2x2
     // stride-2 convolution.  scat (1x1 kernels, 128 outputs): output channel block nc goes to
@@ -214,6 +218,20 @@ __global__ __launch_bounds__(512, 2) void tconv3_kernel(mgx_conv_desc d, const f
                 v[reg] = tt + v[reg] * inv_alpha;
             }
         }
+        if constexpr (KH == 1) {
+            if (blend_alpha != nullptr) {
+                const float al = blend_alpha[0], om = 1.0f - al;
+                const __amdgpu_buffer_rsrc_t ro =
+                    __builtin_amdgcn_make_buffer_rsrc((void*)(blend_old + rowoff), 0, row_bytes, 0x00020000);
+                float old[16];
+#pragma unroll
+                for (int reg = 0; reg < 16; ++reg)
+                    old[reg] = __builtin_bit_cast(float, __builtin_amdgcn_raw_buffer_load_b32(
+                                                             ro, voff, ((reg & 3) + 8 * (reg >> 2)) * rstep, 0));
+#pragma unroll
+                for (int reg = 0; reg < 16; ++reg) v[reg] = mgx_blend(om, old[reg], al, v[reg]);
+            }
+        }
         if (d.accumulate) {
             float old[16];
 #pragma unroll
@@ -329,7 +347,8 @@ __global__ __launch_bounds__(512, 2) void tconv3_kernel(mgx_conv_desc d, const f
 
 template <int KH, int KW, int TH = 8>
 void launch3(const mgx_conv_desc& d, const float* x, const float* xmul, const float* w, const float* bias, float* y,
-             float* dact, hipStream_t st, int gin_w = 0, int scat = 0) {
+             float* dact, hipStream_t st, int gin_w = 0, int scat = 0, const float* blend_old = nullptr,
+             const float* blend_alpha = nullptr) {
     constexpr int TW = 256 / TH;
     const int tiles_h = d.hin / TH, tiles_w = (d.win + TW - 1) / TW;
     const long ntiles = (long)d.nimg * tiles_h * tiles_w;
@@ -342,7 +361,7 @@ void launch3(const mgx_conv_desc& d, const float* x, const float* xmul, const fl
         static std::atomic<uint64_t> allowed{0};                                                                     \
         mgx_allow_dynamic_lds(tconv3_kernel<KH, KW, WW, MM, TH>, lds, allowed);                                      \
         hipLaunchKernelGGL((tconv3_kernel<KH, KW, WW, MM, TH>), dim3(grid), dim3(512), lds, st, d, x, xmul, w, bias, y,   \
-                           dact, ntiles, tiles_h, tiles_w, gin_w, scat);                                             \
+                           dact, ntiles, tiles_h, tiles_w, gin_w, scat, blend_old, blend_alpha);                     \
     } while (0)
     if (wt) { if (mul) MGX_T3(true, true); else MGX_T3(true, false); }
     else { if (mul) MGX_T3(false, true); else MGX_T3(false, false); }
@@ -353,8 +372,14 @@ void launch3(const mgx_conv_desc& d, const float* x, const float* xmul, const fl
 
 // Runs the convolution described by d; applicability is checked by mgx_tconv_applicable (tconv.hip).
 int mgx_tconv3_launch(const mgx_conv_desc& d0, const float* x, const float* xmul, const float* w, const float* bias,
-                      float* y, float* dact, hipStream_t st) {
+                      float* y, float* dact, hipStream_t st, const float* blend_old, const float* blend_alpha) {
     mgx_conv_desc d = d0;
+    if (blend_alpha != nullptr) {          // plain 1x1 convolutions only
+        if (!blend_old || d.kh != 1 || d.kw != 1 || d.sh != 1 || d.dkh != 1 || d.accumulate) return MGX_ERR_ARG;
+        if (d.hin % 8) launch3<1, 1, 4>(d, x, xmul, w, bias, y, dact, st, 0, 0, blend_old, blend_alpha);
+        else launch3<1, 1>(d, x, xmul, w, bias, y, dact, st, 0, 0, blend_old, blend_alpha);
+        return mgx_launch_status();
+    }
     if (d.sh == 2) {
         // 2x2 stride-2 convolution = 1x1 convolution over the 128 channels of the gathered window
         d.hin = d0.hout; d.win = d0.wout; d.cin = 128; d.kh = d.kw = 1; d.sh = d.sw = 1;

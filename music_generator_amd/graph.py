@@ -418,6 +418,26 @@ class Model:
                         skip = i + 1
                         continue
             if (not save and Model.use_conv_chains and not isinstance(op, _FusedOp) and op.act_node is not None
+                    and i + 1 < len(plan)):
+                # the 1x1 convolution that ends a block and the fade-in WeightedSum behind it: the blend runs in the
+                # convolution's epilogue (mgx_conv1x1_blend_bf16 / mgx_conv1x1_blend_f32; bit-identical results)
+                nxt = plan[i + 1]
+                if (not isinstance(nxt, _FusedOp) and getattr(nxt.node.layer, "is_weighted_sum", False)
+                        and len(nxt.inputs) == 2 and nxt.inputs[1] is op.output and nxt.inputs[0] is not op.output
+                        and n_consumers.get(id(op.output), 0) == 1 and op.output is not self.output
+                        and id(nxt.inputs[0]) in vals):
+                    from .layers import conv_blend_eligible, conv_blend_forward
+                    old = vals[id(nxt.inputs[0])]
+                    if conv_blend_eligible(op.node.layer, xs[0], old):
+                        vals[id(nxt.output)] = conv_blend_forward(op.node.layer, op.act_node.layer.alpha_value, xs[0],
+                                                                  old, nxt.node.layer.alpha.value())
+                        for j, o_ in ((i, op), (i + 1, nxt)):
+                            for t in o_.inputs:
+                                if last_use.get(id(t)) == j and t is not self.output:
+                                    vals.pop(id(t), None)
+                        skip = i + 1
+                        continue
+            if (not save and Model.use_conv_chains and not isinstance(op, _FusedOp) and op.act_node is not None
                     and K.bf16_enabled() and xs[0].dtype == torch.bfloat16):
                 chain = self._conv_chain(plan, i, n_consumers, xs[0])
                 if chain is not None:

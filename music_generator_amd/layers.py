@@ -227,6 +227,30 @@ def audio_conv_forward(a, alpha_a, b, alpha_b, x):
     return y
 
 
+def conv_blend_eligible(conv, x, old) -> bool:
+    """`conv` (a 1x1 Conv2D followed by a SoftRectifier) and the WeightedSum that blends its output with `old` as one
+    launch: both operands bf16 with the convolution on the bf16 tile kernel, or both float32 with the convolution on
+    the float32 tile kernel; `old` of the output's shape."""
+    if not isinstance(conv, Conv2D) or x.dim() != 4 or conv.kernel_size != (1, 1) or conv.strides != (1, 1):
+        return False
+    n, h, w, _ = x.shape
+    if x.dtype != old.dtype or tuple(old.shape) != (n, h, w, conv.filters) or not old.is_contiguous():
+        return False
+    if x.dtype == torch.bfloat16:
+        return K.bf16_enabled() and conv._bf16_mode(x, n, h, w) == "conv"
+    if x.dtype == torch.float32:
+        return conv._bf16_mode(x, n, h, w) is None and ops.conv1x1_blend_supported(conv._desc("f", n, h, w))
+    return False
+
+
+def conv_blend_forward(conv, act_alpha, x, old, alpha):
+    n, h, w, _ = x.shape
+    y = K.empty((n, h, w, conv.filters), dtype=x.dtype)
+    blend = ops.conv1x1_blend_bf16 if x.dtype == torch.bfloat16 else ops.conv1x1_blend
+    blend(conv._desc("f", n, h, w), x, conv.kernel.value(), conv.bias.value(), old, alpha, y, act_alpha)
+    return y
+
+
 def conv_chain_eligible(layers, x) -> bool:
     """Two or three layers (each followed by a SoftRectifier) as one launch of the chain kernel: Conv2D(32, k x k,
     same) on 32 channels with kernel sizes {3,3,2}, {3,3} or {3,2}, bf16 input, bf16 precision on."""

@@ -57,6 +57,9 @@ class WeightedSum(Add):
 
     # the executor hands backward() the tape entries of the layers that produced the two inputs (outmuls)
     takes_outmuls = True
+    # in passes that keep no tape the executor may let the convolution that produces the second input blend in its
+    # epilogue (mgx_conv1x1_blend_bf16) instead of running this layer
+    is_weighted_sum = True
 
     def backward(self, saved, dy, need, existing, wgrad, outmuls=(None, None)):
         a, b = saved

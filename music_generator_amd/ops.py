@@ -624,6 +624,43 @@ def conv_gemm_bf16(d: ConvDesc, x, w, bias, y, dact=None, ymul=None, act_alpha=0
                       _conv_bytes_bf16(d, 1, 1 + (1 if dact is not None else 0) + (1 if ymul is not None else 0)))
 
 
+def conv1x1_blend_supported(d: ConvDesc) -> bool:
+    return bool(_lib().mgx_conv1x1_blend_supported(C.byref(d)))
+
+
+def conv1x1_blend(d: ConvDesc, x, w, bias, old, alpha, y, act_alpha):
+    """mgx_conv1x1_blend_f32: y = (1 - alpha) old + alpha act(conv1x1(x)), float32 tensors, alpha on the device."""
+    xe, ye, we = _conv_sizes(d)
+    if x.numel() != xe or y.numel() != ye or old.numel() != ye or w.numel() < we or alpha.numel() != 1:
+        raise MgxError("conv1x1_blend: operand sizes do not match the descriptor")
+    if d.nbias and (bias is None or bias.numel() != d.nbias):
+        raise MgxError("conv1x1_blend: bias size mismatch")
+    d.accumulate = 0
+    d.act_alpha = float(act_alpha)
+    e0 = PROFILER.start() if PROFILER is not None else None
+    check(_lib().mgx_conv1x1_blend_f32(C.byref(d), _p(x), _p(w), _p(bias) if d.nbias else None, _p(old), _p(alpha),
+                                       _p(y), K.stream_ptr()), "mgx_conv1x1_blend_f32")
+    if e0 is not None:
+        key = _gemm_key(d, False)
+        PROFILER.stop(key, _gemm_flops(d, key), e0, _conv_bytes(d, 1, 2))
+
+
+def conv1x1_blend_bf16(d: ConvDesc, x, w, bias, old, alpha, y, act_alpha):
+    """mgx_conv1x1_blend_bf16: y = (1 - alpha) old + alpha act(conv1x1(x)); x, old, y bfloat16, alpha on the device."""
+    xe, ye, we = _conv_sizes(d)
+    if x.numel() != xe or y.numel() != ye or old.numel() != ye or w.numel() < we or alpha.numel() != 1:
+        raise MgxError("conv1x1_blend_bf16: operand sizes do not match the descriptor")
+    if d.nbias and (bias is None or bias.numel() != d.nbias):
+        raise MgxError("conv1x1_blend_bf16: bias size mismatch")
+    d.accumulate = 0
+    d.act_alpha = float(act_alpha)
+    e0 = PROFILER.start() if PROFILER is not None else None
+    check(_lib().mgx_conv1x1_blend_bf16(C.byref(d), _pb(x), _p(w), _p(bias) if d.nbias else None, _pb(old), _p(alpha),
+                                        _pb(y), K.stream_ptr()), "mgx_conv1x1_blend_bf16")
+    if e0 is not None:
+        PROFILER.stop("bconv_kernel<1,1,3>", _conv_flops(d), e0, _conv_bytes_bf16(d, 1, 2))
+
+
 def conv_pair_bf16_supported(n, h, w, kb) -> bool:
     return bool(_lib().mgx_conv_pair_bf16_supported(int(n), int(h), int(w), int(kb)))
 

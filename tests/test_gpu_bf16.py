@@ -696,11 +696,15 @@ def test_bf16_discriminator_forward_with_and_without_chains(bf16_precision):
     from music_generator_amd.graph import Model
     d, g, comp, W = _build(4)
     model = d[3][1]
+    for layer in model.layers:
+        if isinstance(layer, M.WeightedSum):
+            M.backend.set_value(layer.alpha, 0.37)
     real, _ = R.synthetic_inputs(3, 4, seed=2)
     x = torch.from_numpy(real).cuda()
-    calls = []
-    orig = ops.conv_chain_bf16
+    calls, blends = [], []
+    orig, orig_blend = ops.conv_chain_bf16, ops.conv1x1_blend_bf16
     ops.conv_chain_bf16 = lambda *a, **k: (calls.append(tuple(a[4])), orig(*a, **k))[1]
+    ops.conv1x1_blend_bf16 = lambda *a, **k: (blends.append(1), orig_blend(*a, **k))[1]
     chains = Model.use_conv_chains
     try:
         Model.use_conv_chains = True
@@ -715,8 +719,34 @@ def test_bf16_discriminator_forward_with_and_without_chains(bf16_precision):
     finally:
         Model.use_conv_chains = chains
         ops.conv_chain_bf16 = orig
+        ops.conv1x1_blend_bf16 = orig_blend
     assert n_chains >= 6 and set(calls) == {(3, 2), (3, 3, 2), (3, 3)}, calls
+    assert len(blends) == 1            # the fade-in blend of the top block ran in the 1x1 convolution's epilogue
     assert torch.equal(y0, y1), (y0, y1)
+
+
+@pytest.mark.parametrize("n,h,w", [(2, 8, 100), (3, 16, 70), (1, 32, 45), (5, 16, 1500)])
+@pytest.mark.parametrize("alpha", [0.0, 0.37, 1.0])
+def test_bf16_conv1x1_blend_equals_two_launches(n, h, w, alpha):
+    """mgx_conv1x1_blend_bf16 (1x1 convolution 32 -> 128 + activation with the fade-in blend in its epilogue) against
+    mgx_conv_gemm_bf16 followed by mgx_weighted_sum_bf16_fwd: bit for bit, on both tile shapes and ragged widths."""
+    M.clear_session()
+    conv = L.Conv2D(128, (1, 1), padding="same", kernel_initializer="he_normal")
+    conv(Input(shape=(h, w, 32)))
+    rng = np.random.default_rng(n * 1000 + h + w)
+    conv.bias.assign(rng.uniform(-0.5, 0.5, (128,)).astype(np.float32))
+    x = _dev_b(rng.uniform(-1, 1, (n, h, w, 32)))
+    old = _dev_b(rng.uniform(-2, 2, (n, h, w, 128)))
+    al = torch.tensor([alpha], device="cuda")
+    mid = torch.empty((n, h, w, 128), dtype=torch.bfloat16, device="cuda")
+    want = torch.empty_like(mid)
+    ops.conv_gemm_bf16(conv._desc("f", n, h, w), x, conv.kernel.value(), conv.bias.value(), mid, act_alpha=90000.0)
+    ops.weighted_sum_bf16_fwd(old, mid, al, want)
+    got = torch.full_like(want, float("nan"))
+    ops.conv1x1_blend_bf16(conv._desc("f", n, h, w), x, conv.kernel.value(), conv.bias.value(), old, al, got, 90000.0)
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(got.float()).all()), "positions left unwritten"
+    assert torch.equal(got.view(torch.int16), want.view(torch.int16)), float((got.float() - want.float()).abs().max())
 
 
 def test_bf16_weighted_sum_backward_applies_producer_derivatives():

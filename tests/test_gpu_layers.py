@@ -394,3 +394,62 @@ def test_gather_groups_takes_whole_minibatch_stddev_groups(g, m, per, shape):
         assert torch.equal(got, x[torch.as_tensor(idx, device="cuda")])
     with pytest.raises(ops.MgxError):
         ops.gather_groups(x, g, m, m - 1, 2)          # the run would leave its group block
+
+
+@pytest.mark.parametrize("n,h,w", [(2, 8, 100), (3, 16, 70), (2, 4, 45), (2, 12, 33)])
+@pytest.mark.parametrize("alpha", [0.0, 0.37, 1.0])
+def test_conv1x1_blend_equals_two_launches(n, h, w, alpha):
+    """mgx_conv1x1_blend_f32 (1x1 convolution 32 -> 128 + activation with the fade-in blend in its epilogue) against
+    mgx_conv_gemm_f32 followed by mgx_weighted_sum_fwd: bit for bit, on 8-row and 4-row tiles and ragged widths."""
+    from music_generator_amd import ops
+    M.clear_session()
+    conv = L.Conv2D(128, (1, 1), padding="same", kernel_initializer="he_normal")
+    conv(Input(shape=(h, w, 32)))
+    rng = np.random.default_rng(n * 1000 + h + w)
+    conv.bias.assign(rng.uniform(-0.5, 0.5, (128,)).astype(np.float32))
+    x = torch.from_numpy(rng.uniform(-1, 1, (n, h, w, 32)).astype(np.float32)).cuda()
+    old = torch.from_numpy(rng.uniform(-2, 2, (n, h, w, 128)).astype(np.float32)).cuda()
+    al = torch.tensor([alpha], device="cuda")
+    d = conv._desc("f", n, h, w)
+    assert ops.conv1x1_blend_supported(d)
+    mid = torch.empty((n, h, w, 128), device="cuda")
+    want = torch.empty_like(mid)
+    ops.conv_gemm(d, x, conv.kernel.value(), conv.bias.value(), mid, act_alpha=7.0)
+    ops.weighted_sum_fwd(old, mid, al, want)
+    got = torch.full_like(want, float("nan"))
+    ops.conv1x1_blend(d, x, conv.kernel.value(), conv.bias.value(), old, al, got, 7.0)
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(got).all()), "positions left unwritten"
+    assert torch.equal(got, want), float((got - want).abs().max())
+
+
+def test_discriminator_fade_in_forward_with_and_without_blend_epilogue():
+    """A tape-free float32 forward of a fade-in discriminator with the blend in the 1x1 convolution's epilogue
+    (Model.use_conv_chains, the default) and layer by layer: the same logits bit for bit; with a tape the
+    WeightedSum layer runs."""
+    from music_generator_amd import ops
+    M.clear_session()
+    d = M.define_discriminator(3)
+    model = d[2][1]
+    randomize(model, seed=3)
+    for layer in model.layers:
+        if isinstance(layer, M.WeightedSum):
+            M.backend.set_value(layer.alpha, 0.37)
+    x = torch.from_numpy(np.random.default_rng(1).uniform(-1, 1, (4, 16, 3000, 2)).astype(np.float32)).cuda()
+    blends = []
+    orig = ops.conv1x1_blend
+    ops.conv1x1_blend = lambda *a, **k: (blends.append(1), orig(*a, **k))[1]
+    flag = Model.use_conv_chains
+    try:
+        Model.use_conv_chains = True
+        y1 = model(x).clone()
+        assert len(blends) == 1
+        model.forward(x, save=True)
+        assert len(blends) == 1
+        Model.use_conv_chains = False
+        y0 = model(x).clone()
+        assert len(blends) == 1
+    finally:
+        Model.use_conv_chains = flag
+        ops.conv1x1_blend = orig
+    assert torch.equal(y0, y1)
