@@ -361,7 +361,9 @@ class Model:
     use_conv_pairs = False
     # True: runs of two or three consecutive Conv2D(32) + SoftRectifier steps of a tape-free bf16 pass ({3x3, 3x3,
     # 2x2}, {3x3, 3x3}, {3x3, 2x2}: the groups of a discriminator block) go through the row-streaming chain kernel
-    # (mgx_conv_chain_bf16; bit-identical results, the inner layers' outputs never reach HBM).
+    # (mgx_conv_chain_bf16; bit-identical results, the inner layers' outputs never reach HBM).  The same switch
+    # covers the other launch-saving rules of tape-free passes: the from-audio + 3x3 kernel (bf16) and the fade-in
+    # blend in the epilogue of a block's last 1x1 convolution (float32 and bf16).
     use_conv_chains = os.environ.get("MGX_CONV_CHAINS", "1") != "0"      # MGX_CONV_CHAINS=0: layer by layer (measurements)
 
     def _conv_chain(self, plan, i, n_consumers, x):

@@ -66,6 +66,11 @@ class CollapsedGenerator:
         self.table, self.gram = ops.collapse_table(probe, self.ncols)
 
     def __call__(self, z, training: bool = False):
+        if not torch.is_tensor(z):
+            z = torch.from_numpy(np.ascontiguousarray(z, dtype=np.float32))
+        z = z.to(device=K.device(), dtype=torch.float32)
+        if tuple(z.shape[1:]) != self.latent_dim:
+            raise ValueError("latent tensor of shape %s, the generator takes %s" % (tuple(z.shape), self.latent_dim))
         z = z.reshape(z.shape[0], self.ncols * 4).contiguous()
         return ops.collapse_apply(self.table, self.gram, z, self.norm.gamma.value(), self.norm.beta.value(), self.h,
                                   self.wp, self.ncols, self.norm.epsilon)
