@@ -34,18 +34,21 @@ LN_EPS = 1e-3                     # Keras LayerNormalization default epsilon (mo
 ADAM = dict(lr=0.0005, beta_1=0.0, beta_2=0.99, epsilon=10e-8)   # models.py:502-503
 
 
-def stage_hw(stage: int) -> Tuple[int, int]:
-    """Resolution of progressive stage `stage` (dataset.py:85-93; doubling per block)."""
-    return BASE_SHAPE[0] * (1 << stage), BASE_SHAPE[1] * (1 << stage)
+def stage_hw(stage: int, base_shape: Tuple[int, ...] = BASE_SHAPE) -> Tuple[int, int]:
+    """Resolution of progressive stage `stage` (dataset.py:85-93; doubling per block).
+    `base_shape` is the `input_shape` argument of define_discriminator (models.py:309): the
+    discriminator family can be grown from any base resolution, the generator's is fixed."""
+    return base_shape[0] * (1 << stage), base_shape[1] * (1 << stage)
 
 
-def activation_alphas(stage: int) -> Tuple[float, float]:
+def activation_alphas(stage: int, base_h: int = BASE_SHAPE[0]) -> Tuple[float, float]:
     """(StaticOptTanh alpha, SoftRectifier alpha) chosen by add_discriminator_block for the
     block that creates `stage` (>=1); keyed in the reference on the OLD model's height
-    (models.py:232-251).  Stage 0 uses 40000 / 20000 (models.py:341, 200)."""
+    (models.py:232-251), which is `base_h` doubled stage - 1 times.  Stage 0 uses
+    40000 / 20000 (models.py:341, 200)."""
     if stage == 0:
         return 40000.0, 20000.0
-    old_h = BASE_SHAPE[0] * (1 << (stage - 1))
+    old_h = base_h * (1 << (stage - 1))
     alpha, soft = 40000.0, 20000.0
     if old_h == 8:
         alpha, soft = 60000.0, 40000.0
@@ -217,7 +220,7 @@ def _d_block(W, names, s, x):
     """New convolutions of add_discriminator_block for stage s after its from-audio conv
     (models.py:259-281): 3x3,3x3,2x2 | 3x3,3x3,2x2 | 3x3,3x3,2x2/s2 valid | 1x1->128."""
     blk = names["d"][s]
-    _, soft = activation_alphas(s)
+    _, soft = activation_alphas(s, x.shape[1] >> s)
     for i, cname in enumerate(blk["convs"]):
         if i == 8:
             x = _conv_sr(W, cname, x, soft, strides=(2, 2), padding="valid")
@@ -227,13 +230,16 @@ def _d_block(W, names, s, x):
 
 
 def _from_audio(W, names, s, x):
-    _, soft = activation_alphas(s)
+    _, soft = activation_alphas(s, x.shape[1] >> s)
     return _conv_sr(W, names["d"][s]["from_audio"], x, soft)
 
 
 def discriminator(W, names, stage, fade_in, x, alpha=None):
     """define_discriminator()[stage][1 if fade_in else 0] applied to x (models.py:309-354,
-    229-305).  `alpha` is the WeightedSum value of the fade-in twin."""
+    229-305).  `alpha` is the WeightedSum value of the fade-in twin.  The base resolution
+    (define_discriminator's `input_shape`) is read off x: its height is the base height
+    doubled `stage` times."""
+    base_h = x.shape[1] >> stage
     if stage == 0:
         h = _from_audio(W, names, 0, x)
     else:
@@ -244,7 +250,7 @@ def discriminator(W, names, stage, fade_in, x, alpha=None):
         for s in range(stage - 1, 0, -1):                              # old_model.layers[3:]
             h = _d_block(W, names, s, h)
     logit = _d_base_body(W, names, h)
-    sot_alpha, _ = activation_alphas(stage)
+    sot_alpha, _ = activation_alphas(stage, base_h)
     return soft_rectifier(logit, sot_alpha)                            # StaticOptTanh
 
 
@@ -380,8 +386,11 @@ def adam_update(p, g, v, t, lr=ADAM["lr"], beta_2=ADAM["beta_2"], eps=ADAM["epsi
 # --------------------------------------------------------------------------------------
 # weights
 # --------------------------------------------------------------------------------------
-def weight_shapes(n_blocks: int) -> Dict[str, Tuple[int, ...]]:
-    """Shape of every variable of define_discriminator(n)+define_generator(n)."""
+def weight_shapes(n_blocks: int, base_shape: Tuple[int, ...] = BASE_SHAPE) -> Dict[str, Tuple[int, ...]]:
+    """Shape of every variable of define_discriminator(n, input_shape=base_shape) +
+    define_generator(n).  Only Dense(1) of the discriminator depends on the base shape
+    (Flatten of (H+1, W, 32), models.py:338-340); the generator's resolution is fixed by its
+    architecture (models.py:415-451)."""
     nm = layer_names(n_blocks)
     sh: Dict[str, Tuple[int, ...]] = {}
 
@@ -399,7 +408,7 @@ def weight_shapes(n_blocks: int) -> Dict[str, Tuple[int, ...]]:
     ks0 = [3, 4, 3] * 3
     for i, c in enumerate(d0["convs"]):
         conv(c, ks0[i], ks0[i], 128 if i == 0 else 32, 32)
-    dn(d0["dense"], 5 * 750 * 32, 1)
+    dn(d0["dense"], (base_shape[0] + 1) * base_shape[1] * 32, 1)
     for s in range(1, n_blocks):
         b = nm["d"][s]
         conv(b["from_audio"], 1, 1, 2, 128)
@@ -432,14 +441,15 @@ def weight_shapes(n_blocks: int) -> Dict[str, Tuple[int, ...]]:
     return sh
 
 
-def synthetic_weights(n_blocks: int, seed: int = 100, perturb: bool = True) -> Dict[str, np.ndarray]:
+def synthetic_weights(n_blocks: int, seed: int = 100, perturb: bool = True,
+                      base_shape: Tuple[int, ...] = BASE_SHAPE) -> Dict[str, np.ndarray]:
     """Deterministic float32 weights for parity runs.  TF's initialisers cannot be
     reproduced outside TF, so scales only approximate them: kernels ~ N(0, 2/fan_in)
     (he_normal-like, models.py:256 etc.) or U(+-sqrt(6/(fi+fo))) for Dense (glorot).
     With perturb=True biases, gamma and beta get small non-trivial values so that every
     parameter influences the result (Keras would start them at 0 / 1 / 0)."""
     out: Dict[str, np.ndarray] = {}
-    for i, (name, shape) in enumerate(sorted(weight_shapes(n_blocks).items())):
+    for i, (name, shape) in enumerate(sorted(weight_shapes(n_blocks, base_shape).items())):
         rng = np.random.default_rng(seed * 100003 + i)
         kind = name.rsplit("/", 1)[1]
         if kind == "kernel":
@@ -617,10 +627,10 @@ def generator_step_grads(weights: Dict[str, np.ndarray], n_blocks: int, stage: i
     return {n: g.detach().numpy().copy() for n, g in zip(g_names, grads)}
 
 
-def synthetic_inputs(stage: int, batch: int, seed: int = 0):
+def synthetic_inputs(stage: int, batch: int, seed: int = 0, base_shape: Tuple[int, ...] = BASE_SHAPE):
     """real ~ U(-1,1) (N,H,W,2) and four latent draws ~ N(0,1) (N,1,100,2), float32, from
     numpy default_rng(seed) / default_rng(seed+1..seed+4)."""
-    h, w = stage_hw(stage)
+    h, w = stage_hw(stage, base_shape)
     real = np.random.default_rng(seed).uniform(-1.0, 1.0, (batch, h, w, 2)).astype(np.float32)
     z4 = [np.random.default_rng(seed + 1 + i).standard_normal((batch,) + LATENT_DIM).astype(np.float32)
           for i in range(4)]
