@@ -578,6 +578,92 @@ def test_bf16_full_resolution_step_properties(bf16_precision):
         FusedGroup.side_budget_bytes = None
 
 
+def test_bf16_full_resolution_step_at_batch_256(bf16_precision):
+    """The full-resolution bench configuration itself: stage 6 (256 x 48000) fade-in step, batch 256 in 64
+    micro-batches of one MinibatchStdDev group, generator tape bounded to 8 GiB, bf16.  Properties that do
+    not depend on the size: the six metrics finite, delta = |cu - ci| (models.py:469-472), every gradient
+    finite and not all zero, exactly one update of each optimiser, and the step's peak HBM within 150 GiB."""
+    from music_generator_amd.graph import FusedGroup
+    stage, n = 6, 256
+    try:
+        gan = _fresh_gan(stage, 4, 8.0)
+        gen = torch.Generator(device="cuda")
+        gen.manual_seed(4)
+        real = torch.rand((n, 256, 48000, 2), device="cuda", generator=gen).mul_(2.0).sub_(1.0)
+        torch.cuda.synchronize()
+        torch.cuda.reset_peak_memory_stats()
+        m = {k: float(v) for k, v in gan.train_step(real).items()}
+        peak = torch.cuda.max_memory_allocated() / 2.0 ** 30
+        print("batch-256 full-resolution step: peak %.1f GiB" % peak, m)
+        assert all(np.isfinite(v) for v in m.values()), m
+        for i in ("0", "1"):
+            assert abs(m["delta_" + i] - abs(m["cu_" + i] - m["ci_" + i])) < 1e-5, m
+        for model in (gan.discriminator, gan.generator):
+            flat = model.bind_grads(0)
+            assert bool(torch.isfinite(flat).all()) and float(flat.abs().max()) > 0.0
+        assert gan.actual_step == 4 and gan.d_optimizer.iterations == 1 and gan.g_optimizer.iterations == 1
+        assert peak <= 150.0, peak
+    finally:
+        FusedGroup.side_budget_bytes = None
+        del real
+        torch.cuda.empty_cache()
+
+
+def test_bf16_third_step_with_warmed_adam_matches_emulated_oracle(bf16_precision):
+    """Adam at t = 3 on the bf16 path, generator-step gradients included.  The float64 oracle advances weights
+    and both optimisers' second moments two steps on the host; the device takes that state over and runs the
+    third step with bf16 precision, which is compared with the oracle's third step with bf16 storage emulated.
+    With warmed second moments the discriminator update in front of the generator step is no longer sign-like
+    (see test_bf16_train_step_matches_emulated_oracle), so the generator-step gradients are comparable:
+    relative L2 <= 8e-2 for discriminator-step AND generator-step gradients (1.2e-1 for bias / beta gradients;
+    the scalar alphas, cancelling sums over a whole activation, are pinned by test_bf16_weighted_sum), metrics
+    and losses abs 5e-3, updated weights abs 2e-5 + 8e-2 of the oracle's own update."""
+    import os
+    import sys
+    from oracle import bf16_emulation as E
+    sys.path.insert(0, os.path.join(os.path.dirname(os.path.abspath(__file__)), "golden"))
+    import make_golden
+    _, n_blocks, stage, batch, n_steps = make_golden.T3
+    cur, vd, vg = make_golden.warmed_state(n_blocks, stage, batch, n_steps, 2)
+    d, g, comp, _ = _build(n_blocks)
+    gan = comp[stage][1]
+    for model in (gan.discriminator, gan.generator):
+        for v in model.trainable_variables:
+            v.assign(cur[v.name])
+    gan.d_optimizer.set_second_moments(gan.discriminator, vd, 2)
+    gan.g_optimizer.set_second_moments(gan.generator, vg, 2)
+    gan.set_train_steps(n_steps)
+    gan.actual_step = 2
+    real, z4 = R.synthetic_inputs(stage, batch, seed=12)
+    gan.inject_latents(z4)
+    metrics = {k: float(v) for k, v in gan.train_step(real).items()}
+    with E.bf16_storage():
+        res = R.train_step(cur, n_blocks, stage, True, real, z4, alpha=2 / float(n_steps - 1), v_d=vd, v_g=vg, t=3)
+    for k, v in res.metrics.items():
+        assert abs(metrics[k] - v) < 5e-3, (k, metrics[k], v)
+    assert abs(float(gan.last_losses["d_loss"]) - res.d_loss) < 5e-3
+    assert abs(float(gan.last_losses["g_loss"]) - res.g_loss) < 5e-3
+    assert gan.d_optimizer.iterations == 3 and gan.g_optimizer.iterations == 3
+    worst, worst_u = {}, {}
+    UPDATE_TOL = 2.5e-1
+    for which, model, grads in (("d", gan.discriminator, res.d_grads), ("g", gan.generator, res.g_grads)):
+        for v in model.trainable_variables:
+            want = grads[v.name]
+            if np.abs(want).max() < 1e-12 or v.name.endswith("/alpha"):
+                continue
+            err = rel_l2(v.grad.cpu().numpy().reshape(want.shape), want)
+            worst[which] = max(worst.get(which, (0.0, "")), (err, v.name))
+            tol = 1.2e-1 if v.name.endswith(("/bias", "/beta")) else 8e-2
+            assert err < tol, "%s-step gradient of %s: rel-L2 %.3e" % (which, v.name, err)
+            start = np.asarray(cur[v.name], np.float64)
+            uerr = rel_l2(v.numpy() - start, res.weights[v.name] - start)
+            if v.size >= 64:
+                worst_u[which] = max(worst_u.get(which, (0.0, "")), (uerr, v.name))
+    print("worst relative L2 of gradients (d-step, g-step):", worst, "of updates:", worst_u)
+    for which, (uerr, name) in worst_u.items():
+        assert uerr < UPDATE_TOL, "%s-step update of %s: rel-L2 %.3e" % (which, name, uerr)
+
+
 @pytest.mark.parametrize("h,w,n,kb", [(16, 64, 1, 3), (16, 31, 2, 2), (20, 45, 2, 3), (32, 100, 3, 2), (48, 333, 1, 3),
                                       (17, 30, 1, 3), (64, 500, 2, 2)])
 def test_bf16_conv_pair_equals_two_launches(h, w, n, kb):
