@@ -71,6 +71,9 @@ def parse_args():
                     help="evaluate discriminator(real) once after the D update instead of three times (same values)")
     ap.add_argument("--cpu-sample-batch", type=int, default=2)
     ap.add_argument("--c3-batch", type=int, default=256)
+    ap.add_argument("--c3-steps", type=int, default=1, help="timed full-resolution steps of the c3 / c4 objects")
+    ap.add_argument("--c5-clips", type=int, default=4096, help="clips of the bf16 leg of the c5 object (the float32 leg "
+                                                               "is a 64-clip sample)")
     ap.add_argument("--infer", action="store_true", help="generator-only inference line (BASELINE configs[4])")
     ap.add_argument("--clips", type=int, default=256, help="--infer: clips to generate in the timed region")
     ap.add_argument("--chunk", type=int, default=8, help="--infer: clips per generator call")
@@ -105,7 +108,11 @@ def cpu_baseline(stage, fade, sample_batch, n_blocks, timed=3):
     path cannot run here: TensorFlow/Keras are not installed)."""
     import torch
     from oracle import ref_step as R
-    cores = min(16, os.cpu_count() or 1)          # a one-GPU box grants 16 cores of the host
+    # the cores this process may use: its affinity mask, or the thread count the box's operator set
+    # (os.cpu_count() is the whole machine, of which a one-GPU lease is granted a share)
+    cores = len(os.sched_getaffinity(0)) if hasattr(os, "sched_getaffinity") else (os.cpu_count() or 1)
+    if os.environ.get("OMP_NUM_THREADS", "").isdigit():
+        cores = min(cores, int(os.environ["OMP_NUM_THREADS"]))
     torch.set_num_threads(cores)
     W = R.synthetic_weights(n_blocks, seed=100)
     real, z4 = R.synthetic_inputs(stage, sample_batch, seed=0)
@@ -203,6 +210,7 @@ def progress(msg):
 T_START = time.perf_counter()
 
 
+C3_DIGEST = "r3_c3" if os.path.exists(os.path.join(ROOT, "profiles", "r3_c3_digest.json")) else "r2_c3"
 C3_MICRO_BATCH = 4          # samples per micro-batch of the full-resolution step (whole MinibatchStdDev groups)
 
 
@@ -238,51 +246,137 @@ def per_stage_table(torch, M):
     return out
 
 
-def c3_run(torch, M, ops, batch, micro_batch=C3_MICRO_BATCH):
+def c3_run(torch, M, ops, batch, micro_batch=C3_MICRO_BATCH, steps=1, dist=None, stage=6, rank=0):
     """BASELINE configs[2]: stage 6 (256 x 48000), batch `batch`, bf16, micro-batches of one MinibatchStdDev
     group (4 samples), generator tape bounded to 8 GiB (re-computing backward).  Warm-up: one step on 8
-    samples (same micro-batch shapes); then ONE timed step on the whole batch."""
-    stage = 6
+    samples (same micro-batch shapes); then `steps` timed steps on the whole batch.
+    With `dist` (a DataParallel over more than one rank) this is BASELINE configs[3]: every rank steps on
+    `batch` samples of its own with the gradient all-reduces of the data-parallel step, and the time is the
+    maximum over ranks."""
     torch.cuda.empty_cache()
+    tag = "c4" if dist is not None else "c3"
     gan = build_gan(M, stage, True, "bfloat16", micro_batch, 8.0)
+    h, w = 4 << stage, 750 << stage
+    if dist is not None:
+        gan.dist = dist
+        dist.broadcast_weights(gan.discriminator, gan.generator)
+        dist.record_waits = True
+    gan.seed(4321 + rank)
     gen = torch.Generator(device="cuda")
-    gen.manual_seed(7)
-    real = torch.rand((batch, 256, 48000, 2), device="cuda", generator=gen).mul_(2.0).sub_(1.0)
-    warm = max(8, micro_batch)
-    progress("c3: batch of %d clips resident, warm-up step on %d samples" % (batch, warm))
+    gen.manual_seed(7 + rank)
+    real = torch.rand((batch, h, w, 2), device="cuda", generator=gen).mul_(2.0).sub_(1.0)
+    warm = min(batch, max(8, micro_batch))
+
+    def sync():
+        if dist is not None:
+            dist.barrier()
+        torch.cuda.synchronize()
+
+    if rank == 0:
+        progress("%s: batch of %d clips resident, warm-up step on %d samples" % (tag, batch, warm))
     gan.train_step(real[:warm])
-    torch.cuda.synchronize()
+    sync()
+    if dist is not None:
+        dist.take_wait_stall_ms()
     torch.cuda.reset_peak_memory_stats()
-    progress("c3: timed step on %d samples (about a minute)" % batch)
+    if rank == 0:
+        progress("%s: %d timed step(s) on %d samples (about 40 s each)" % (tag, steps, batch))
     prof = ops.LaunchProfiler()
     ops.PROFILER = prof
     t0 = time.perf_counter()
-    metrics = gan.train_step(real)
-    torch.cuda.synchronize()
-    dt = time.perf_counter() - t0
+    for _ in range(steps):
+        metrics = gan.train_step(real)
+    sync()
+    dt = (time.perf_counter() - t0) / steps
     ops.PROFILER = None
-    progress("c3: %.1f s per step, %.2f samples/s" % (dt, batch / dt))
+    comm = None
+    if dist is not None:
+        t = torch.tensor([dt], device="cuda" if torch.distributed.get_backend() == "nccl" else "cpu", dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        dt = float(t.item())
+        comm = collective_report(torch, gan, dist, steps)
+    if rank == 0:
+        progress("%s: %.1f s per step, %.2f samples/s per GPU" % (tag, dt, batch / dt))
     summ = prof.summary()
-    key, roof = roofline_of(summ, 1, dt * 1e3, BF16_MFMA_PEAK_TFLOPS)
+    key, roof = roofline_of(summ, steps, dt * 1e3, BF16_MFMA_PEAK_TFLOPS)
     # counter passes of the same step at batch 16 (the launches are those of the batch-256 step)
     roof["traffic"] = measured_traffic(key, "stage6_fade_mb4_bf16")
-    roof["mfma_busy_frac_sq_counters"] = measured_mfma_busy(key, "r2_c3")
+    roof["mfma_busy_frac_sq_counters"] = measured_mfma_busy(key, C3_DIGEST)
     top = sorted(summ.items(), key=lambda kv: -kv[1][1])[:8]
-    out = {"workload": "stage-6 (256x48000) fade-in G+D train step, batch %d (micro-batches of %d), bf16 storage / "
-                       "bf16 MFMA / f32 accumulation, f32 master weights" % (batch, micro_batch),
-           "value": round(batch / dt, 3), "unit": "samples/s", "steps": 1, "warmup": "1 step on %d samples" % warm,
+    world = dist.world_size if dist is not None else 1
+    out = {"workload": "stage-%d (%dx%d) fade-in G+D train step, batch %d per GPU (micro-batches of %d), bf16 storage / "
+                       "bf16 MFMA / f32 accumulation, f32 master weights" % (stage, h, w, batch, micro_batch),
+           "value": round(world * batch / dt, 3), "unit": "samples/s", "steps": steps,
+           "warmup": "1 step on %d samples" % warm,
            "ms_per_step": round(dt * 1e3, 1), "dtype": "bf16",
-           "step_tflops_algorithmic": round(STEP_GFLOP_PER_SAMPLE[stage] * batch / dt / 1e3, 1),
+           "step_tflops_algorithmic": round(world * STEP_GFLOP_PER_SAMPLE[stage] * batch / dt / 1e3, 1),
            "frac_of_bf16_mfma_peak": round(STEP_GFLOP_PER_SAMPLE[stage] * batch / dt / 1e3 / BF16_MFMA_PEAK_TFLOPS, 4),
            "peak_hbm_gib": round(torch.cuda.max_memory_allocated() / 2 ** 30, 1),
            "roofline": roof,
-           "top_kernels": {k: {"ms": round(v[1], 1), "TFLOP/s": round(v[2] / v[1] / 1e9, 1),
+           "top_kernels": {k: {"ms": round(v[1] / steps, 1), "TFLOP/s": round(v[2] / v[1] / 1e9, 1),
                                "GB/s": round(v[3] / v[1] / 1e6, 1)} for k, v in top},
            "last_metrics": {k: float(v) for k, v in metrics.items()}}
+    if dist is not None:
+        out.update({"n_gpus": world, "global_batch": world * batch, "rccl_ranks": torch.distributed.get_world_size(),
+                    "collective_backend": torch.distributed.get_backend(), "collectives": comm})
     del gan, real
     torch.cuda.empty_cache()
     M.backend.set_precision("float32")
     return out
+
+
+def collective_report(torch, gan, dist, steps):
+    """What the gradient all-reduces of the timed data-parallel steps cost: bytes per step, the time the compute
+    stream stood still in front of mgx_combine_grads / Adam waiting for them (events around every wait), and the
+    same three buffers reduced once more on an otherwise idle GPU for comparison; the share of the stand-alone
+    time that did NOT show up as a stall is the overlap achieved."""
+    stall_ms = dist.take_wait_stall_ms() / steps
+    bufs = [gan.discriminator.bind_grads(0), gan.discriminator.bind_grads(1), gan.generator.bind_grads(0)]
+    gan.discriminator.bind_grads(0)
+    nbytes = sum(b.numel() * 4 for b in bufs)
+    alone_ms = None
+    if torch.distributed.get_backend() == "nccl":
+        scratch = [torch.zeros_like(b) for b in bufs]
+        for t in scratch:
+            torch.distributed.all_reduce(t)
+        torch.cuda.synchronize()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record()
+        for t in scratch:
+            torch.distributed.all_reduce(t)
+        e1.record()
+        torch.cuda.synchronize()
+        alone_ms = e0.elapsed_time(e1)
+    return {"allreduce_bytes_per_step": nbytes, "buffers": {"discriminator_fake_pass": bufs[0].numel() * 4,
+                                                          "discriminator_real_pass": bufs[1].numel() * 4,
+                                                          "generator": bufs[2].numel() * 4},
+            "logit_sum_allreduces_per_step": 4,
+            "compute_stream_stall_ms_per_step": round(stall_ms, 3),
+            "same_allreduces_alone_ms": None if alone_ms is None else round(alone_ms, 3),
+            "overlap_achieved": None if not alone_ms else round(max(0.0, 1.0 - stall_ms / alone_ms), 3)}
+
+
+def c1_run(torch, M, steps=100):
+    """BASELINE configs[0] on the GPU: stage 0 (4 x 750) straight-through step at the reference's batch of 16,
+    float32, the way train_step runs it by default at this size (one HIP graph replayed per step)."""
+    torch.cuda.empty_cache()
+    gan = build_gan(M, 0, False, "float32")
+    gan.seed(5)
+    real = torch.rand((16, 4, 750, 2), device="cuda") * 2.0 - 1.0
+    for _ in range(4):
+        gan.train_step(real)
+    torch.cuda.synchronize()
+    t0 = time.perf_counter()
+    for _ in range(steps):
+        metrics = gan.train_step(real)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - t0) / steps
+    replayed = any(e.get("graph") is not None for e in gan._graphs.values())
+    return {"workload": "stage-0 (4x750) straight-through G+D train step, batch 16, fp32%s"
+                        % (", HIP graph replay" if replayed else ""),
+            "value": round(16 / dt, 1), "unit": "samples/s", "steps": steps, "ms_per_step": round(dt * 1e3, 3),
+            "dtype": "f32", "step_tflops_algorithmic": round(STEP_GFLOP_PER_SAMPLE[0] * 16 / dt / 1e3, 2),
+            "last_metrics": {k: float(v) for k, v in metrics.items()}}
 
 
 def infer_run(torch, M, ops, precision, stage, clips, chunk):
@@ -317,7 +411,9 @@ def infer_run(torch, M, ops, precision, stage, clips, chunk):
            "data": "synthetic (standard-normal latent vectors)",
            "config": {"workload": "generator-only inference, stage %d (%dx%d), %d clips in chunks of %d, audio reduced "
                                   "to per-clip checksums on the device" % (stage, h, w, clips, chunk)},
+           "clips": n, "seconds": round(dt, 2),
            "seconds_for_4096_clips": round(4096 * dt / n, 1),
+           "seconds_for_4096_clips_is": "measured" if n == 4096 else "extrapolated from %d clips" % n,
            "gflop_per_clip": round(sum(v[2] for v in summ.values()) / n / 1e9, 1),
            "tflops_algorithmic": round(sum(v[2] for v in summ.values()) / dt / 1e12, 1),
            "finite": bool(np_isfinite(chk)), "clip_mean_abs_max": float(abs(chk[:, 0]).max() / (h * w * 2)),
@@ -453,6 +549,14 @@ def main():
         elapsed = float(t.item())
     last = {k: float(v) for k, v in metrics.items()}
     ranks = torch.distributed.get_world_size() if dist is not None else 1
+    c4 = None
+    if dist is not None and not args.no_extras and not args.graph:
+        # BASELINE configs[3]: the full-resolution bf16 step, batch 256 per GPU, data-parallel over all ranks
+        # (MGX_BENCH_C4="stage,batch,micro-batch" shrinks it for rehearsals on a box with fewer GPUs than ranks)
+        c4_stage, c4_batch, c4_mb = (int(v) for v in os.environ.get("MGX_BENCH_C4", "6,%d,%d" % (args.c3_batch, C3_MICRO_BATCH)).split(","))
+        del gan, real
+        c4 = c3_run(torch, M, ops, c4_batch, c4_mb, steps=args.c3_steps, dist=dist, stage=c4_stage, rank=rank)
+        gan = real = None
     if dist is not None:
         torch.distributed.destroy_process_group()
     if not all(np.isfinite(list(last.values()))):
@@ -480,6 +584,8 @@ def main():
     if world > 1:
         out["rccl_ranks"] = ranks
         out["collective_backend"] = backend_name
+        if c4 is not None:
+            out["c4"] = c4
     if prof is not None:
         summ = prof.summary()
         if args.kernels:
@@ -505,14 +611,19 @@ def main():
         out["roofline"] = roof
     if world == 1 and not args.graph:
         del gan, real
+        gan = real = None
         if not args.no_extras:
             out["per_stage"] = per_stage_table(torch, M)
-            out["c3"] = c3_run(torch, M, ops, args.c3_batch)
+            out["c1"] = c1_run(torch, M)
+            progress("c1: %.2f ms per step" % out["c1"]["ms_per_step"])
+            out["c3"] = c3_run(torch, M, ops, args.c3_batch, steps=args.c3_steps)
             out["c5"] = {}
             for precision in ("float32", "bfloat16"):
-                r = infer_run(torch, M, ops, precision, 6, 64, 8)
+                # bf16: the whole 4096-clip run of BASELINE configs[4]; float32: a 64-clip sample of it
+                r = infer_run(torch, M, ops, precision, 6, 64 if precision == "float32" else args.c5_clips, 8)
                 out["c5"]["f32" if precision == "float32" else "bf16"] = {
-                    k: r[k] for k in ("value", "unit", "seconds_for_4096_clips", "gflop_per_clip", "tflops_algorithmic", "roofline",
+                    k: r[k] for k in ("value", "unit", "clips", "seconds", "seconds_for_4096_clips",
+                                      "seconds_for_4096_clips_is", "gflop_per_clip", "tflops_algorithmic", "roofline",
                                       "hbm_ops", "peak_hbm_gib", "finite")}
                 out["c5"]["workload"] = r["config"]["workload"]
                 progress("c5 %s: %.1f clips/s" % (precision, r["value"]))

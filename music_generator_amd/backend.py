@@ -176,10 +176,12 @@ class _SideLane:
     def __enter__(self):
         if _lane[0] != 0:
             raise RuntimeError("the second lane cannot be forked from itself")
-        self.stream.wait_stream(torch.cuda.current_stream())
+        self.origin = torch.cuda.current_stream()
+        self.stream.wait_stream(self.origin)
         self._ctx = torch.cuda.stream(self.stream)
         self._ctx.__enter__()
         _lane[0] = self.lane
+        _open_lanes[id(self.stream)] = self
         return self
 
     def __exit__(self, *exc):
@@ -189,6 +191,29 @@ class _SideLane:
 
     def join(self):
         torch.cuda.current_stream().wait_stream(self.stream)
+        _open_lanes.pop(id(self.stream), None)
+
+
+# Lanes that were forked and not yet joined, by stream.  Under HIP graph capture a forked stream that is not
+# joined back to the stream the capture began on before the capture ends is an error of the capture (an
+# unjoined fork; this ROCm release can crash inside hipStreamEndCapture instead of reporting it), also for a
+# lane that only ran leaf work nothing waits for: join_all() closes whatever is open.
+_open_lanes: Dict[int, "_SideLane"] = {}
+
+
+def join_all():
+    """Make the current stream wait for every lane forked and not joined so far."""
+    for lane in list(_open_lanes.values()):
+        lane.join()
+
+
+def open_lanes() -> int:
+    return len(_open_lanes)
+
+
+def current_lane() -> int:
+    """0 on the caller's stream, 1 / 2 inside `with fork(lane):`."""
+    return _lane[0]
 
 
 def fork(lane: int = 1) -> _SideLane:

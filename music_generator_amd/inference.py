@@ -56,10 +56,17 @@ class CollapsedGenerator:
         self.refresh()
 
     def refresh(self):
+        """Measure the table with the float32 layer kernels, whatever precision is set globally: probes run
+        through the bf16 generator kernels would carry their rounding (~1e-3) into every clip written later."""
         probe_z = torch.zeros((5, self.ncols, 4), dtype=torch.float32, device=K.device())
         for k in range(4):
             probe_z[1 + k, :, k] = 1.0
-        probe = self.pre_model(probe_z.reshape((5,) + self.latent_dim), training=False).contiguous()
+        precision = K.precision()
+        K.set_precision("float32")
+        try:
+            probe = self.pre_model(probe_z.reshape((5,) + self.latent_dim), training=False).contiguous()
+        finally:
+            K.set_precision(precision)
         if probe.shape[2] % self.ncols:
             raise ValueError("output width %d is not a multiple of the %d latent column pairs" % (probe.shape[2], self.ncols))
         self.h, self.wp = int(probe.shape[1]), int(probe.shape[2]) // self.ncols

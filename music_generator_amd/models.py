@@ -310,8 +310,22 @@ def _register_fused_block(block_end, upsampling, for_sum_layer):
     def weights():
         if "w" not in state:
             state["w"] = pointers(lambda v: v.value())
-            state["pack"] = K.empty((ops.gblock_pack_floats(),))
         return state["w"]
+
+    # Every forward / backward call re-packs the block's weights into a scratch buffer before its kernel
+    # reads them.  The streams of two lanes are not ordered against each other between fork() and join(), so
+    # each lane packs into a buffer of its own: no lane shares writable scratch with another.
+    def pack():
+        key = ("pack", K.current_lane())
+        if key not in state:
+            state[key] = K.empty((ops.gblock_pack_floats(),))
+        return state[key]
+
+    def packb(x):
+        key = ("packb", K.current_lane())
+        if key not in state:
+            state[key] = torch.empty((ops.gblock_pack_bf16_bytes(),), dtype=torch.uint8, device=x.device)
+        return state[key]
 
     def run(x):
         w = weights()
@@ -320,13 +334,8 @@ def _register_fused_block(block_end, upsampling, for_sum_layer):
         if K.bf16_enabled():
             ops.gblock_fwd_bf16(w, packb(x), x, y, n, hl, wl)
         else:
-            ops.gblock_fwd(w, state["pack"], x, y, n, hl, wl)
+            ops.gblock_fwd(w, pack(), x, y, n, hl, wl)
         return y
-
-    def packb(x):
-        if "packb" not in state:
-            state["packb"] = torch.empty((ops.gblock_pack_bf16_bytes(),), dtype=torch.uint8, device=x.device)
-        return state["packb"]
 
     def run_save(x):
         """Taped forward.  With enough memory the block's intermediate tensors are kept (one
@@ -352,22 +361,19 @@ def _register_fused_block(block_end, upsampling, for_sum_layer):
         if bf:
             ops.gblock_fwd_bf16(w, packb(x), x, y, n, hl, wl, act=act)
         else:
-            ops.gblock_fwd(w, state["pack"], x, y, n, hl, wl, act=act)
+            ops.gblock_fwd(w, pack(), x, y, n, hl, wl, act=act)
         return y, (act, None, (n, hl, wl), bf, None)
 
     def backward(saved, dy, need_weight_grads):
         act, x, (n, hl, wl), bf, budget = saved
         w = weights()
-        if bf:
-            if "packtb" not in state:
-                state["packtb"] = torch.empty((ops.gblock_packt_bf16_bytes(),), dtype=torch.uint8, device=dy.device)
-            packt = state["packtb"]
-        else:
-            if "packt" not in state:
-                state["packt"] = K.empty((ops.gblock_packt_floats(),))
-            packt = state["packt"]
+        key = ("packtb" if bf else "packt", K.current_lane())
+        if key not in state:
+            state[key] = torch.empty((ops.gblock_packt_bf16_bytes(),), dtype=torch.uint8, device=dy.device) if bf \
+                else K.empty((ops.gblock_packt_floats(),))
+        packt = state[key]
         fwd = (lambda **kw: ops.gblock_fwd_bf16(w, packb(dy), x, None, n, hl, wl, **kw)) if bf else \
-              (lambda **kw: ops.gblock_fwd(w, state["pack"], x, None, n, hl, wl, **kw))
+              (lambda **kw: ops.gblock_fwd(w, pack(), x, None, n, hl, wl, **kw))
         dgrad = ops.gblock_dgrad_bf16 if bf else ops.gblock_dgrad
         wgrad = ops.gblock_wgrad_bf16 if bf else ops.gblock_wgrad
         side_of = ops.gblock_side_elems_bf16 if bf else ops.gblock_side_floats
@@ -817,6 +823,7 @@ class WGAN:
 
     GRAPH_AUTO_BATCH = 16
     OVERLAP_AUTO_BATCH = 16
+    SCALAR_SLOTS = 8            # pinned slots for the per-step scalars of a replayed graph (see _graphed_step)
     # the automatic graph mode stops below the full-resolution stage (batch x rows x columns of the audio): a
     # captured step keeps its activations in a memory pool of its own, which at 256 x 48000 does not fit beside
     # the eager step's, and a step of a second gains nothing from replay
@@ -847,11 +854,16 @@ class WGAN:
             return False
         return bool(self.merge_passes)
 
+    def _optimizers_replayable(self) -> bool:
+        """A captured step reads its Adam step sizes from device memory, which the update kernel offers for
+        beta_1 = 0 only (define_composite's setting, models.py:502-503)."""
+        return all(getattr(o, "beta_1", None) == 0.0 for o in (self.d_optimizer, self.g_optimizer))
+
     def _graph_wanted(self, real) -> bool:
         if self.use_graph is not None:
             return bool(self.use_graph)
         return (real.shape[0] <= self.GRAPH_AUTO_BATCH and real.numel() // 2 <= self.GRAPH_AUTO_POSITIONS
-                and self.dist is None and self.d_steps == 1
+                and self.dist is None and self.d_steps == 1 and self._optimizers_replayable()
                 and not self._latents and ops.PROFILER is None and not self.keep_logits
                 and not self.micro_batch and not torch.cuda.is_current_stream_capturing())
 
@@ -885,6 +897,9 @@ class WGAN:
             raise RuntimeError("injected latents cannot be used with use_graph (the graph draws its own)")
         if ops.PROFILER is not None:
             raise RuntimeError("per-launch profiling and graph capture exclude each other")
+        if not self._optimizers_replayable():
+            raise NotImplementedError("graph replay needs both optimisers with beta_1 = 0 (the update kernel reads "
+                                      "its step size from device memory only without a first moment)")
         # a graph is valid for one batch shape, one set of step-shaping options and one generation of the
         # scratch buffers whose addresses its launches carry
         key = (tuple(real.shape), self.micro_batch, self.generator_chunk, self.reuse_real_logits,
@@ -908,7 +923,13 @@ class WGAN:
             if "real" not in entry:
                 entry["real"] = torch.empty_like(real)
                 entry["scal"] = torch.zeros((3,), dtype=torch.float32, device=real.device)
-                entry["host"] = torch.zeros((3,), dtype=torch.float32).pin_memory()
+                # The per-step scalars travel through pinned host memory with an asynchronous copy.  The host may
+                # run several replays ahead of the GPU (nothing in a replay waits for it), so one slot would be
+                # rewritten before the copy of an earlier step has read it: a ring of slots, each guarded by an
+                # event recorded behind its copy, and a slot is reused only after that event has passed.
+                entry["host"] = torch.zeros((self.SCALAR_SLOTS, 3), dtype=torch.float32).pin_memory()
+                entry["host_events"] = [None] * self.SCALAR_SLOTS
+                entry["host_next"] = 0
             graph = torch.cuda.CUDAGraph()
             if self._rng is not None:
                 graph.register_generator_state(self._rng)
@@ -921,6 +942,9 @@ class WGAN:
                         for layer in self._fade_layers():
                             layer.alpha.value().copy_(entry["scal"][0:1])
                     entry["out"] = self._step_body(entry["real"])
+                    # a stream forked inside the capture and not joined back makes hipStreamEndCapture fail (or
+                    # crash): whatever the step left open is joined here
+                    K.join_all()
             finally:
                 self._scalars = None
             if K.buffer_generation() != generation:
@@ -928,11 +952,18 @@ class WGAN:
                                    "eager step before the capture must see the same shapes")
             entry["graph"], entry["generation"] = graph, generation
             entry["scratch"] = K.live_scratch()      # referenced as long as this graph may replay
-        host = entry["host"]
+        slot = entry["host_next"]
+        entry["host_next"] = (slot + 1) % self.SCALAR_SLOTS
+        if entry["host_events"][slot] is not None:
+            entry["host_events"][slot].synchronize()
+        host = entry["host"][slot]
         host[0] = 0.0 if alpha is None else alpha
         host[1] = self.d_optimizer.next_step_size()
         host[2] = self.g_optimizer.next_step_size()
         entry["scal"].copy_(host, non_blocking=True)
+        ev = torch.cuda.Event()
+        ev.record()
+        entry["host_events"][slot] = ev
         entry["real"].copy_(real)
         entry["graph"].replay()
         self.actual_step += 1

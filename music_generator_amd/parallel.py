@@ -51,6 +51,10 @@ class DataParallel:
         # collectives are skipped in a group of one unless forced (a one-rank group still runs every call
         # through the backend: the way to execute the RCCL path on a box with a single GPU)
         self.active = dist.is_initialized() and (self.world_size > 1 or force_collectives)
+        # True: every wait_for() is bracketed by two events on the waiting stream, so that the time the stream
+        # stood still for a collective can be read afterwards (take_wait_stall_ms)
+        self.record_waits = False
+        self._wait_events = []
 
     def all_reduce(self, t: torch.Tensor):
         """In-place sum over ranks, enqueued on the current stream (RCCL) / blocking (gloo)."""
@@ -75,11 +79,27 @@ class DataParallel:
             return dist.all_reduce(t, op=dist.ReduceOp.SUM, async_op=True)
         return None
 
-    @staticmethod
-    def wait_for(handle):
+    def wait_for(self, handle):
         """Order the current stream behind an all_reduce_async (blocks the host only for gloo)."""
         if handle is not None:
-            handle.wait()
+            if self.record_waits and torch.cuda.is_available():
+                e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+                e0.record()
+                handle.wait()
+                e1.record()
+                self._wait_events.append((e0, e1))
+            else:
+                handle.wait()
+
+    def take_wait_stall_ms(self) -> float:
+        """Milliseconds the waiting stream spent between 'reached the wait' and 'the collective had finished',
+        summed over the waits recorded since the last call (synchronises the device)."""
+        if not self._wait_events:
+            return 0.0
+        torch.cuda.synchronize()
+        total = sum(e0.elapsed_time(e1) for e0, e1 in self._wait_events)
+        self._wait_events = []
+        return float(total)
 
     def shard(self, global_batch):
         idx = shard_indices(global_batch.shape[0], self.rank, self.world_size)

@@ -21,6 +21,7 @@ if rccl_one:
     os.environ.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")
     dp = DataParallel(backend="nccl", force_collectives=True)
     assert dp.active and torch.distributed.get_backend() == "nccl"
+    dp.record_waits = True
 else:
     dp = DataParallel(backend="gloo") if world > 1 else None
 n_blocks, stage, batch = 2, 1, 16
@@ -51,6 +52,10 @@ print("rank", 0 if dp is None else dp.rank, "step begin", flush=True)
 metrics = {k: float(v) for k, v in gan.train_step(real).items()}
 torch.cuda.synchronize()
 print("rank", 0 if dp is None else dp.rank, "step end", flush=True)
+if rccl_one:
+    stall = dp.take_wait_stall_ms()
+    assert stall >= 0.0 and not dp._wait_events
+    print("stall ms in front of the gradient combines:", stall, flush=True)
 if dp is None or dp.rank == 0:
     arrays = {"m|" + k: np.float64(v) for k, v in metrics.items()}
     for model in (gan.discriminator, gan.generator):

@@ -153,6 +153,23 @@ def test_collapsed_generator_equals_layer_path(stage, fade):
     assert np.abs(cg(zt).cpu().numpy() - model(zt, training=False).cpu().numpy()).max() < 5e-5
 
 
+def test_collapsed_generator_table_is_float32_under_bf16_precision():
+    """CollapsedGenerator.refresh() with bf16 precision set globally: the probes still run through the float32
+    layer kernels, so the table equals the one built under float32 bit for bit and the precision setting is
+    left as it was."""
+    from music_generator_amd.inference import CollapsedGenerator
+    d, g, comp, W = build(3)
+    model = g[2][0]
+    want = CollapsedGenerator(model)
+    M.backend.set_precision("bfloat16")
+    try:
+        got = CollapsedGenerator(model)
+        assert M.backend.precision() == "bfloat16"
+    finally:
+        M.backend.set_precision("float32")
+    assert torch.equal(got.table, want.table) and torch.equal(got.gram, want.gram)
+
+
 def test_generate_clips_collapsed_sink_order_and_full_resolution():
     """generate_clips(collapse=True): same chunking contract; at the full-resolution stage (256 x 48000) two
     clips equal the layer path (relative L2 below 1e-5) and are normalised (mean 0, variance 1 - eps effect below 1e-3,

@@ -595,6 +595,71 @@ def test_graph_replayed_step_equals_eager_step(stage, fade):
         assert np.array_equal(a, b)
 
 
+def test_graph_replays_without_host_reads_follow_the_eager_trajectory():
+    """24 replays on device-resident batches with no host read in between: the host runs replays ahead of the
+    GPU, so the per-step scalars (fade-in alpha, the two Adam step sizes, which change by a factor of 3 over the
+    first ten updates) must reach each replay through a pinned slot of its own.  Weights after the run must
+    equal the eager run's bit for bit; the ring of slots is walked three times."""
+    stage, fade, steps = 1, True, 26
+    batches = [torch.from_numpy(R.synthetic_inputs(stage, 4, seed=200 + k)[0]).cuda() for k in range(4)]
+    runs = []
+    for use_graph in (False, True):
+        d, g, comp, _ = build(stage + 1)
+        gan = comp[stage][1]
+        gan.seed(9)
+        gan.use_graph = use_graph
+        gan.set_train_steps(steps)
+        torch.cuda.synchronize()
+        for k in range(steps):
+            gan.train_step(batches[k % 4])
+        torch.cuda.synchronize()
+        runs.append([v.numpy() for model in (gan.discriminator, gan.generator) for v in model.trainable_variables])
+        if use_graph:
+            entry = next(e for e in gan._graphs.values() if e.get("graph") is not None)
+            assert steps - 2 >= 3 * gan.SCALAR_SLOTS and all(ev is not None for ev in entry["host_events"])
+    for a, b in zip(*runs):
+        assert np.array_equal(a, b)
+
+
+def test_graph_mode_leaves_optimizers_with_a_first_moment_alone():
+    """The automatic graph mode steps aside for optimisers whose update cannot read its step size from device
+    memory (beta_1 != 0): such a WGAN trains eagerly at any batch size, and forcing use_graph raises before
+    anything is captured."""
+    d, g, comp, _ = build(1)
+    gan = M.WGAN(discriminator=d[0][0], generator=g[0][0], latent_dim=(1, 100, 2), discriminator_extra_steps=1)
+    gan.compile(d_optimizer=M.Adam(lr=0.0005, beta_1=0.5, beta_2=0.99), g_optimizer=M.Adam(lr=0.0005, beta_1=0.5, beta_2=0.99))
+    gan.seed(3)
+    real, _ = R.synthetic_inputs(0, 4, seed=1)
+    for _ in range(3):
+        out = gan.train_step(real)
+    assert all(np.isfinite(float(v)) for v in out.values())
+    assert gan.d_optimizer.iterations == 3 and not any(e.get("graph") for e in gan._graphs.values())
+    gan.use_graph = True
+    with pytest.raises(NotImplementedError):
+        gan.train_step(real)
+    assert gan.d_optimizer.iterations == 3 and not gan._graphs
+
+
+def test_no_lane_stays_forked_after_a_step():
+    """Every stream a step forks (the real-batch lane, the generator-ahead lane) is joined again before the step
+    returns, eagerly and inside a capture (a capture that ends with an unjoined fork fails)."""
+    from music_generator_amd import backend as K
+    d, g, comp, _ = build(2)
+    gan = comp[1][1]
+    gan.seed(1)
+    gan.set_train_steps(4)
+    real, _ = R.synthetic_inputs(1, 4, seed=2)
+    for _ in range(3):                      # eager, capture, replay
+        gan.train_step(real)
+        assert K.open_lanes() == 0
+    lane = K.fork(2)
+    with lane:
+        pass
+    assert K.open_lanes() == 1
+    K.join_all()
+    assert K.open_lanes() == 0
+
+
 @pytest.mark.parametrize("stage,fade,use_graph", [(0, False, False), (1, True, False), (1, True, True)])
 def test_real_pass_on_second_stream_changes_nothing(stage, fade, use_graph):
     """WGAN.overlap_passes: every discriminator pass over the real batch on the second stream (own gradient
@@ -736,13 +801,18 @@ def test_bench_starts_its_own_ranks():
     import subprocess
     import sys
     root = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
-    env = dict(os.environ, MGX_BENCH_BACKEND="gloo")
+    env = dict(os.environ, MGX_BENCH_BACKEND="gloo", MGX_BENCH_C4="2,8,4")
     env.pop("WORLD_SIZE", None)
     res = subprocess.run([sys.executable, os.path.join(root, "bench.py"), "--gpus", "2", "--stage", "1", "--batch", "8",
-                          "--steps", "2", "--warmup", "1"], env=env, capture_output=True, text=True, timeout=150)
+                          "--steps", "2", "--warmup", "1"], env=env, capture_output=True, text=True, timeout=300)
     assert res.returncode == 0, res.stderr[-2000:]
     lines = [l for l in res.stdout.splitlines() if l.startswith("{")]
     assert len(lines) == 1, res.stdout[-2000:]
     out = json.loads(lines[0])
     assert out["n_gpus"] == 2 and out["rccl_ranks"] == 2 and out["collective_backend"] == "gloo"
     assert out["config"]["global_batch"] == 16 and out["value"] > 0
+    # the full-resolution data-parallel object of the multi-rank line, rehearsed at stage 2 (16 x 3000), batch 8 per rank
+    c4 = out["c4"]
+    assert c4["n_gpus"] == 2 and c4["global_batch"] == 16 and c4["rccl_ranks"] == 2 and c4["value"] > 0
+    assert c4["collectives"]["allreduce_bytes_per_step"] > 0 and c4["dtype"] == "bf16"
+    assert all(np.isfinite(v) for v in c4["last_metrics"].values())
