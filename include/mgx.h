@@ -351,11 +351,14 @@ int mgx_adam_multi_devlr(float* const* p, const int64_t* n, const int64_t* off, 
 int mgx_conv_bf16_supported(const mgx_conv_desc* d);
 
 /* The contraction of mgx_conv_gemm_f32 on bf16 activations (Conv2D + SoftRectifier of models.py:259-281):
- * x, y bf16; w, bias float32.  With d->act_alpha > 0 the epilogue is tanh(v)+v/alpha and dact (may be
- * NULL) receives the derivative as bf16.  ymul (may be NULL; then no bias / activation): the result is
- * multiplied element-wise by this bf16 tensor of the output's shape before it is stored: the
- * data-gradient of a convolution whose input came out of an activation, dX = (W^T dY) (.) f'.
- * d->accumulate must be 0. */
+ * x, y bf16; w, bias float32.  With d->act_alpha > 0 (and no ymul) the epilogue is tanh(v)+v/alpha and dact
+ * (may be NULL) receives the derivative as bf16.  ymul (may be NULL; with it no bias and no dact): the result
+ * is multiplied element-wise, before it is stored, by a factor taken from this bf16 tensor of the output's
+ * shape: the data-gradient of a convolution whose input came out of an activation, dX = (W^T dY) (.) f'.
+ * With d->act_alpha == 0 ymul holds the factor itself (a stored derivative); with d->act_alpha > 0 ymul holds
+ * that activation's stored OUTPUT y = tanh(v)+v/alpha and the factor is the derivative recovered from it,
+ * max(1 + 1/alpha - y^2, 1/alpha): backward passes that keep no derivative tensor (the layer input the
+ * weight gradient needs anyway is that output).  d->accumulate must be 0. */
 int mgx_conv_gemm_bf16(const mgx_conv_desc* d, const void* x, const float* w, const float* bias, void* y,
                        void* dact, const void* ymul, void* stream);
 /* The 1x1 convolution + SoftRectifier that ends a discriminator block (models.py:280-281) and the WeightedSum
@@ -432,6 +435,12 @@ int mgx_weighted_sum_bf16_bwd(const void* dy, const void* a, const void* b, cons
 int mgx_weighted_sum_bf16_bwd_mul(const void* dy, const void* a, const void* b, const float* alpha, void* da, void* db,
                                   float* dalpha, const void* ma, const void* mb, void* workspace,
                                   int64_t workspace_bytes, int64_t n, void* stream);
+/* The same for producers that keep no derivative tensor: a / b ARE the stored outputs of the SoftRectifiers
+ * (models.py:295, 281) that produced them, and the factors are the derivatives recovered from them with
+ * act_alpha_a / act_alpha_b (0 = that side is not multiplied), as in mgx_conv_gemm_bf16. */
+int mgx_weighted_sum_bf16_bwd_act(const void* dy, const void* a, const void* b, const float* alpha, void* da, void* db,
+                                  float* dalpha, float act_alpha_a, float act_alpha_b, void* workspace,
+                                  int64_t workspace_bytes, int64_t n, void* stream);
 
 /* The generator grow block of mgx_gblock_fwd_f32 / _dgrad_f32 / _wgrad_f32 (add_generator_block,
  * models.py:362-399, and its part of tape.gradient, models.py:144-146) on bf16 MFMAs with float32
@@ -455,6 +464,9 @@ int mgx_gblock_wgrad_bf16(const void* act, const void* delta, const mgx_gblock_g
  * product dY (.) f' of tf.GradientTape through a SoftRectifier (models.py:205-206) where the kernel that
  * produced dY could not apply the saved derivative itself. */
 int mgx_mul_bf16(const void* a, int a_is_f32, const void* b, void* out, int64_t n, void* stream);
+/* out = a (.) f'(y): the same product where no derivative tensor is kept; y is the SoftRectifier's stored bf16
+ * output and f' is recovered from it as in mgx_conv_gemm_bf16 (act_alpha > 0). */
+int mgx_mul_dact_bf16(const void* a, int a_is_f32, const void* y, float act_alpha, void* out, int64_t n, void* stream);
 
 /* Casts at the boundary between the bf16 grow blocks and the float32 base block (no counterpart in the
  * reference, which runs float32 throughout). */

@@ -139,6 +139,7 @@ PROTOTYPES = {
     "mgx_weighted_sum_bf16_fwd": (_I, [_P, _P, _P, _P, _I64, _P]),
     "mgx_weighted_sum_bf16_bwd": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _I64, _I64, _P]),
     "mgx_weighted_sum_bf16_bwd_mul": (_I, [_P, _P, _P, _P, _P, _P, _P, _P, _P, _P, _I64, _I64, _P]),
+    "mgx_weighted_sum_bf16_bwd_act": (_I, [_P, _P, _P, _P, _P, _P, _P, _F, _F, _P, _I64, _I64, _P]),
     "mgx_gblock_pack_bf16_bytes": (_I64, []),
     "mgx_gblock_packt_bf16_bytes": (_I64, []),
     "mgx_gblock_side_elems_bf16": (_I64, [_I64]),
@@ -146,6 +147,7 @@ PROTOTYPES = {
     "mgx_gblock_dgrad_bf16": (_I, [C.POINTER(GBlockWeights), _P, _P, _P, _P, _I64, _I, _I, _I64, _I64, _P]),
     "mgx_gblock_wgrad_bf16": (_I, [_P, _P, C.POINTER(GBlockWeights), _P, _I64, _I64, _P]),
     "mgx_mul_bf16": (_I, [_P, _I, _P, _P, _I64, _P]),
+    "mgx_mul_dact_bf16": (_I, [_P, _I, _P, _F, _P, _I64, _P]),
     "mgx_cast_f32_to_bf16": (_I, [_P, _P, _I64, _P]),
     "mgx_cast_bf16_to_f32": (_I, [_P, _P, _I64, _P]),
 }

@@ -126,6 +126,12 @@ def get_value(var: Variable):
 # float32).
 _precision = ["float32"]
 BF16_MIN_ROWS = 8
+# What a taped bf16 convolution + SoftRectifier keeps for its backward pass beside its input.  False (default):
+# nothing; the derivative 1 - tanh(v)^2 + 1/alpha is recovered from the layer's stored bf16 OUTPUT (which the next
+# layer's tape holds anyway as its input) as max(1 + 1/alpha - y^2, 1/alpha): half the tape and a third less HBM
+# traffic in every taped forward.  True: the derivative is written as a bf16 tensor of its own by the forward
+# epilogue (one more rounding-exact value per element, twice the tape).
+BF16_SAVE_DERIVATIVE = False
 
 
 def set_precision(name: str):

@@ -20,7 +20,8 @@
 // offsets; columns past the row end are dropped by the store's range check.
 // Epilogues: bias + tanh(x)+x/alpha (+ optional store of the derivative for the backward pass);
 // multiply by a bf16 tensor of the output's shape (the data-gradient of a convolution whose input came
-// out of an activation: dY (.) f'); plain; or (1x1 kernels, passes that keep no tape) bias + activation followed by
+// out of an activation: dY (.) f'), either the stored derivative itself or the activation's stored output, from
+// which the derivative is recovered; plain; or (1x1 kernels, passes that keep no tape) bias + activation followed by
 // the fade-in blend (1 - alpha) old + alpha y of trainer/models.py:30-35 with a bf16 tensor `old` of the output's
 // shape, in place of a WeightedSum launch that would read the activation back.
 #include <cstdlib>
@@ -45,8 +46,9 @@ __global__ __launch_bounds__(64 * TH) void bconv_kernel(mgx_conv_desc d, const b
                                                        const bf16_t* __restrict__ ymul, long ntiles, int tiles_h,
                                                        int tiles_w, int gin_w, int scat,
                                                        const float* __restrict__ blend_alpha) {
-    // EPI: 0 plain, 1 bias + activation (+ derivative), 2 multiply by ymul, 3 = 1 followed by the blend with ymul
-    constexpr bool ACT = EPI == 1 || EPI == 3, PRE = EPI == 2 || EPI == 3;
+    // EPI: 0 plain, 1 bias + activation (+ derivative), 2 multiply by ymul, 3 = 1 followed by the blend with ymul,
+    // 4 multiply by the activation derivative recovered from ymul = the activation's stored OUTPUT (dact_from_y)
+    constexpr bool ACT = EPI == 1 || EPI == 3, PRE = EPI == 2 || EPI == 3 || EPI == 4;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     constexpr int TW = NT * 32, NTHR = 64 * TH;
     constexpr int IH = TH + KH - 1, IW = TW + KW - 1, TAPS = KH * KW, NPIX = IH * IW;
@@ -230,6 +232,15 @@ __global__ __launch_bounds__(64 * TH) void bconv_kernel(mgx_conv_desc d, const b
                     o[i] = bf_pack(a[2 * i] * bf_lo(m0[i]), a[2 * i + 1] * bf_hi(m0[i]));
                     o[4 + i] = bf_pack(a[8 + 2 * i] * bf_lo(m1[i]), a[8 + 2 * i + 1] * bf_hi(m1[i]));
                 }
+            } else if (EPI == 4) {
+                const u32x4 m0 = pre_m[nt][0], m1 = pre_m[nt][1];
+#pragma unroll
+                for (int i = 0; i < 4; ++i) {
+                    o[i] = bf_pack(a[2 * i] * dact_from_y(bf_lo(m0[i]), inv_alpha, k1),
+                                   a[2 * i + 1] * dact_from_y(bf_hi(m0[i]), inv_alpha, k1));
+                    o[4 + i] = bf_pack(a[8 + 2 * i] * dact_from_y(bf_lo(m1[i]), inv_alpha, k1),
+                                       a[8 + 2 * i + 1] * dact_from_y(bf_hi(m1[i]), inv_alpha, k1));
+                }
             } else {
 #pragma unroll
                 for (int i = 0; i < 16; i += 2) o[i >> 1] = bf_pack(a[i], a[i + 1]);
@@ -293,7 +304,8 @@ int launch_shape(const mgx_conv_desc& d, const bf16_t* x, const float* w, const 
     const unsigned grid = (unsigned)(ntiles < 256 ? ntiles : 256);
     const int lds = KH * KW * d.cin * d.ngemm * 2 + 2 * npix<KH, KW, TH, NT>() * 64 + d.ngemm * 4;
     if (lds > 160 * 1024) return MGX_ERR_ARG;
-    const int epi = blend_alpha != nullptr ? 3 : (ymul != nullptr ? 2 : ((d.nbias > 0 || d.act_alpha > 0.f) ? 1 : 0));
+    const int epi = blend_alpha != nullptr ? 3
+                    : (ymul != nullptr ? (d.act_alpha > 0.f ? 4 : 2) : ((d.nbias > 0 || d.act_alpha > 0.f) ? 1 : 0));
 #define MGX_B(E)                                                                                                     \
     do {                                                                                                             \
         if (hipFuncSetAttribute((const void*)bconv_kernel<KH, KW, E, TH, NT>,                                        \
@@ -305,7 +317,8 @@ int launch_shape(const mgx_conv_desc& d, const bf16_t* x, const float* w, const 
     if (epi == 3) {
         if constexpr (KH == 1 && KW == 1) MGX_B(3);
         else return MGX_ERR_ARG;
-    } else if (epi == 2) MGX_B(2);
+    } else if (epi == 4) MGX_B(4);
+    else if (epi == 2) MGX_B(2);
     else if (epi == 1) MGX_B(1);
     else MGX_B(0);
 #undef MGX_B
@@ -350,7 +363,7 @@ extern "C" int mgx_conv_gemm_bf16(const mgx_conv_desc* dp, const void* x, const 
     if (!dp || !x || !w || !y || !mgx_conv_bf16_supported(dp)) return MGX_ERR_ARG;
     if (dp->accumulate) return MGX_ERR_ARG;
     if (dp->nbias > 0 && (!bias || dp->nbias != dp->ngemm)) return MGX_ERR_ARG;
-    if (ymul && (dp->nbias > 0 || dp->act_alpha > 0.f)) return MGX_ERR_ARG;
+    if (ymul && (dp->nbias > 0 || dact)) return MGX_ERR_ARG;
     hipStream_t st = (hipStream_t)stream;
     mgx_conv_desc d = *dp;
     const bf16_t* xb = (const bf16_t*)x;

@@ -43,9 +43,11 @@ __global__ __launch_bounds__(kBlock) void cast_b2f_kernel(const bf16_t* __restri
 
 // out = a (.) b with b, out bf16 and a bf16 or float32: dY (.) f'(pre-activation) where the data-gradient
 // kernel upstream could not apply the multiplier itself.
-template <bool AF32>
+// DER: b holds the activation's stored output and the factor is the derivative recovered from it (dact_from_y).
+template <bool AF32, bool DER>
 __global__ __launch_bounds__(kBlock) void mul_b_kernel(const void* __restrict__ a, const bf16_t* __restrict__ b,
-                                                       bf16_t* __restrict__ out, long n8) {
+                                                       bf16_t* __restrict__ out, long n8, float inv_alpha) {
+    const float k1 = 1.0f + inv_alpha;
     for (long i = (long)blockIdx.x * kBlock + threadIdx.x; i < n8; i += (long)gridDim.x * kBlock) {
         const u32x4 bv = ((const u32x4*)b)[i];
         float av[8];
@@ -60,7 +62,11 @@ __global__ __launch_bounds__(kBlock) void mul_b_kernel(const void* __restrict__ 
         }
         u32x4 o;
 #pragma unroll
-        for (int k = 0; k < 4; ++k) o[k] = bf_pack(av[2 * k] * bf_lo(bv[k]), av[2 * k + 1] * bf_hi(bv[k]));
+        for (int k = 0; k < 4; ++k) {
+            float m0 = bf_lo(bv[k]), m1 = bf_hi(bv[k]);
+            if (DER) { m0 = dact_from_y(m0, inv_alpha, k1); m1 = dact_from_y(m1, inv_alpha, k1); }
+            o[k] = bf_pack(av[2 * k] * m0, av[2 * k + 1] * m1);
+        }
         ((u32x4*)out)[i] = o;
     }
 }
@@ -209,14 +215,21 @@ __global__ __launch_bounds__(kBlock) void wsum_b_bwd_kernel(const bf16_t* __rest
                                                             bf16_t* __restrict__ da, bf16_t* __restrict__ db,
                                                             double* __restrict__ part, long n8,
                                                             const bf16_t* __restrict__ ma,
-                                                            const bf16_t* __restrict__ mb) {
+                                                            const bf16_t* __restrict__ mb, float ia_a, float ia_b) {
     // ma / mb: the saved activation derivative of the layer that produced a / b.  The gradient leaves as
     // bf16(bf16((1 - alpha) dy) * ma): rounded where a multiply launch of its own would have rounded it.
+    // ia_a / ia_b (1 / alpha of the activation that produced a / b; 0 = none), used where ma / mb is null: the
+    // factor is the derivative recovered from a / b themselves, which are those activations' stored outputs.
     __shared__ double red[4];
     const float al = alpha[0], om = 1.0f - al;
+    const bool der_a = da && !ma && ia_a > 0.f, der_b = db && !mb && ia_b > 0.f;
+    const float k1a = 1.0f + ia_a, k1b = 1.0f + ia_b;
     float s = 0.f;
     for (long i = (long)blockIdx.x * kBlock + threadIdx.x; i < n8; i += (long)gridDim.x * kBlock) {
         const u32x4 g = ((const u32x4*)dy)[i];
+        u32x4 av = {0u, 0u, 0u, 0u}, bv = {0u, 0u, 0u, 0u};
+        if (part || der_a) av = ((const u32x4*)a)[i];
+        if (part || der_b) bv = ((const u32x4*)b)[i];
         if (da) {
             u32x4 o;
 #pragma unroll
@@ -225,6 +238,11 @@ __global__ __launch_bounds__(kBlock) void wsum_b_bwd_kernel(const bf16_t* __rest
                 const u32x4 m = ((const u32x4*)ma)[i];
 #pragma unroll
                 for (int k = 0; k < 4; ++k) o[k] = bf_pack(bf_lo(o[k]) * bf_lo(m[k]), bf_hi(o[k]) * bf_hi(m[k]));
+            } else if (der_a) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    o[k] = bf_pack(bf_lo(o[k]) * dact_from_y(bf_lo(av[k]), ia_a, k1a),
+                                   bf_hi(o[k]) * dact_from_y(bf_hi(av[k]), ia_a, k1a));
             }
             ((u32x4*)da)[i] = o;
         }
@@ -236,11 +254,15 @@ __global__ __launch_bounds__(kBlock) void wsum_b_bwd_kernel(const bf16_t* __rest
                 const u32x4 m = ((const u32x4*)mb)[i];
 #pragma unroll
                 for (int k = 0; k < 4; ++k) o[k] = bf_pack(bf_lo(o[k]) * bf_lo(m[k]), bf_hi(o[k]) * bf_hi(m[k]));
+            } else if (der_b) {
+#pragma unroll
+                for (int k = 0; k < 4; ++k)
+                    o[k] = bf_pack(bf_lo(o[k]) * dact_from_y(bf_lo(bv[k]), ia_b, k1b),
+                                   bf_hi(o[k]) * dact_from_y(bf_hi(bv[k]), ia_b, k1b));
             }
             ((u32x4*)db)[i] = o;
         }
         if (part) {
-            const u32x4 av = ((const u32x4*)a)[i], bv = ((const u32x4*)b)[i];
             float t = 0.f;
 #pragma unroll
             for (int k = 0; k < 4; ++k) {
@@ -285,11 +307,25 @@ extern "C" int mgx_mul_bf16(const void* a, int a_is_f32, const void* b, void* ou
     if (!a || !b || !out || n <= 0 || n % 8) return MGX_ERR_ARG;
     const long n8 = n / 8;
     if (a_is_f32)
-        hipLaunchKernelGGL((mul_b_kernel<true>), dim3(grid_for(n8)), dim3(kBlock), 0, (hipStream_t)stream, a,
-                           (const bf16_t*)b, (bf16_t*)out, n8);
+        hipLaunchKernelGGL((mul_b_kernel<true, false>), dim3(grid_for(n8)), dim3(kBlock), 0, (hipStream_t)stream, a,
+                           (const bf16_t*)b, (bf16_t*)out, n8, 0.f);
     else
-        hipLaunchKernelGGL((mul_b_kernel<false>), dim3(grid_for(n8)), dim3(kBlock), 0, (hipStream_t)stream, a,
-                           (const bf16_t*)b, (bf16_t*)out, n8);
+        hipLaunchKernelGGL((mul_b_kernel<false, false>), dim3(grid_for(n8)), dim3(kBlock), 0, (hipStream_t)stream, a,
+                           (const bf16_t*)b, (bf16_t*)out, n8, 0.f);
+    return mgx_launch_status();
+}
+
+extern "C" int mgx_mul_dact_bf16(const void* a, int a_is_f32, const void* y, float act_alpha, void* out, int64_t n,
+                                 void* stream) {
+    if (!a || !y || !out || n <= 0 || n % 8 || !(act_alpha > 0.f)) return MGX_ERR_ARG;
+    const long n8 = n / 8;
+    const float ia = 1.0f / act_alpha;
+    if (a_is_f32)
+        hipLaunchKernelGGL((mul_b_kernel<true, true>), dim3(grid_for(n8)), dim3(kBlock), 0, (hipStream_t)stream, a,
+                           (const bf16_t*)y, (bf16_t*)out, n8, ia);
+    else
+        hipLaunchKernelGGL((mul_b_kernel<false, true>), dim3(grid_for(n8)), dim3(kBlock), 0, (hipStream_t)stream, a,
+                           (const bf16_t*)y, (bf16_t*)out, n8, ia);
     return mgx_launch_status();
 }
 
@@ -358,11 +394,14 @@ extern "C" int mgx_weighted_sum_bf16_bwd(const void* dy, const void* a, const vo
                                          n, stream);
 }
 
-extern "C" int mgx_weighted_sum_bf16_bwd_mul(const void* dy, const void* a, const void* b, const float* alpha, void* da,
-                                             void* db, float* dalpha, const void* ma, const void* mb, void* workspace,
-                                             int64_t workspace_bytes, int64_t n, void* stream) {
+namespace {
+int wsum_b_bwd_launch(const void* dy, const void* a, const void* b, const float* alpha, void* da, void* db,
+                      float* dalpha, const void* ma, const void* mb, float act_alpha_a, float act_alpha_b, void* workspace,
+                      int64_t workspace_bytes, int64_t n, void* stream) {
     if (!dy || !alpha || n <= 0 || n % 8) return MGX_ERR_ARG;
     if ((ma && !da) || (mb && !db)) return MGX_ERR_ARG;
+    if (act_alpha_a < 0.f || act_alpha_b < 0.f) return MGX_ERR_ARG;
+    if ((act_alpha_a > 0.f && (!da || !a)) || (act_alpha_b > 0.f && (!db || !b))) return MGX_ERR_ARG;
     if (dalpha && (!a || !b || !workspace)) return MGX_ERR_ARG;
     if (dalpha && workspace_bytes < (int64_t)(kMaxGrid * sizeof(double))) return MGX_ERR_WORKSPACE;
     const unsigned grid = grid_for(n / 8);
@@ -370,7 +409,22 @@ extern "C" int mgx_weighted_sum_bf16_bwd_mul(const void* dy, const void* a, cons
     hipStream_t st = (hipStream_t)stream;
     hipLaunchKernelGGL(wsum_b_bwd_kernel, dim3(grid), dim3(kBlock), 0, st, (const bf16_t*)dy, (const bf16_t*)a,
                        (const bf16_t*)b, alpha, (bf16_t*)da, (bf16_t*)db, part, (long)(n / 8), (const bf16_t*)ma,
-                       (const bf16_t*)mb);
+                       (const bf16_t*)mb, act_alpha_a > 0.f ? 1.0f / act_alpha_a : 0.f,
+                       act_alpha_b > 0.f ? 1.0f / act_alpha_b : 0.f);
     if (dalpha) hipLaunchKernelGGL(finish_sum_b_kernel, dim3(1), dim3(64), 0, st, part, (int)grid, dalpha);
     return mgx_launch_status();
+}
+}  // namespace
+
+extern "C" int mgx_weighted_sum_bf16_bwd_mul(const void* dy, const void* a, const void* b, const float* alpha, void* da,
+                                             void* db, float* dalpha, const void* ma, const void* mb, void* workspace,
+                                             int64_t workspace_bytes, int64_t n, void* stream) {
+    return wsum_b_bwd_launch(dy, a, b, alpha, da, db, dalpha, ma, mb, 0.f, 0.f, workspace, workspace_bytes, n, stream);
+}
+
+extern "C" int mgx_weighted_sum_bf16_bwd_act(const void* dy, const void* a, const void* b, const float* alpha, void* da,
+                                             void* db, float* dalpha, float act_alpha_a, float act_alpha_b, void* workspace,
+                                             int64_t workspace_bytes, int64_t n, void* stream) {
+    return wsum_b_bwd_launch(dy, a, b, alpha, da, db, dalpha, nullptr, nullptr, act_alpha_a, act_alpha_b, workspace,
+                             workspace_bytes, n, stream);
 }

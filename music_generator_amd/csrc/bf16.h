@@ -97,6 +97,15 @@ __device__ __forceinline__ void act_bf16(float x, float inv_alpha, float k1, flo
     dv = __builtin_fmaf(-t, t, k1);
 }
 
+// The derivative 1 - tanh(v)^2 + 1/alpha recovered from the STORED activation output y = bf16(tanh(v) + v/alpha), for
+// backward passes that keep no derivative tensor: 1 + 1/alpha - y^2.  The v/alpha term of y shifts it by 2 tanh(v) v/alpha
+// (below the 2 |y| 2^-9 that the rounding of y itself contributes for every alpha the reference uses, 11 000 and up);
+// the true derivative is never below 1/alpha, which the maximum restores where a y rounded up past 1 would turn
+// the difference negative.  inv_alpha = 1/alpha, k1 = 1 + 1/alpha.
+__device__ __forceinline__ float dact_from_y(float y, float inv_alpha, float k1) {
+    return __builtin_fmaxf(__builtin_fmaf(-y, y, k1), inv_alpha);
+}
+
 // ds_read_b64_tr_b16: per group of 16 lanes a block of 4 rows x 16 columns of 16-bit elements; lane 4q+p
 // supplies the address of row q, columns 4p..4p+3 (8-byte aligned), lane i receives column i of the 4 rows.
 // All 64 lanes must be active.

@@ -144,19 +144,21 @@ class _Contraction(Layer):
         n, h, w, _ = x.shape
         ho, wo = self._out_hw(h, w)
         y = K.empty((n, ho, wo, self.filters), dtype=torch.bfloat16)
-        dact = K.empty(y.shape, dtype=torch.bfloat16) if (save and act_alpha > 0.0) else None
+        keep = save and act_alpha > 0.0
+        dact = K.empty(y.shape, dtype=torch.bfloat16) if (keep and K.BF16_SAVE_DERIVATIVE) else None
         if mode == "audio":
             ops.pointwise2_bf16_fwd(x, self.kernel.value(), self.bias.value(), y, dact, n * h * w, act_alpha)
         else:
             ops.conv_gemm_bf16(self._desc("f", n, h, w), x, self.kernel.value(), self.bias.value(), y, dact=dact,
                                act_alpha=act_alpha)
-        return y, (_BSaved(mode, x, dact) if save else None)
+        return y, (_BSaved(mode, x, dact, y if (keep and dact is None) else None, act_alpha) if save else None)
 
     def _backward_bf16(self, saved, dy, need, existing, wgrad, outmul):
         x = saved.x
         n, h, w, _ = x.shape
-        if saved.dact is not None and not saved.premultiplied:
-            g = ops.mul_bf16(dy, saved.dact)          # dY (.) f': the kernel upstream could not apply it
+        if saved.has_derivative() and not saved.premultiplied:
+            # dY (.) f': the kernel upstream could not apply it
+            g = ops.mul_bf16(dy, saved.dact) if saved.dact is not None else ops.mul_dact_bf16(dy, saved.yact, saved.alpha)
         else:
             g = dy if dy.dtype == torch.bfloat16 else ops.cast_to_bf16(dy)
         do_w = wgrad and self.trainable
@@ -177,11 +179,12 @@ class _Contraction(Layer):
         if existing[0] is not None:
             raise NotImplementedError("gradient fan-in into a bf16 activation")
         dx = K.empty(x.shape, dtype=torch.bfloat16)
-        ymul = None
-        if outmul is not None and outmul.dact is not None and not outmul.premultiplied:
-            ymul = outmul.dact
+        ymul, mul_alpha = None, 0.0
+        if outmul is not None and outmul.has_derivative() and not outmul.premultiplied:
+            # the stored derivative, or the producer's stored output (= this layer's input) it is recovered from
+            ymul, mul_alpha = (outmul.dact, 0.0) if outmul.dact is not None else (outmul.yact, outmul.alpha)
             outmul.premultiplied = True      # the producer of x receives dX (.) f' and must not multiply again
-        ops.conv_gemm_bf16(self._desc("d", n, h, w), g, self.kernel.value(), None, dx, ymul=ymul)
+        ops.conv_gemm_bf16(self._desc("d", n, h, w), g, self.kernel.value(), None, dx, ymul=ymul, act_alpha=mul_alpha)
         return [(dx, True)]
 
 
@@ -283,13 +286,18 @@ class _CastSaved(tuple):
 
 
 class _BSaved:
-    """Tape entry of a contraction that ran on the bf16 kernels: its input, the saved derivative of the
-    fused activation (or None) and whether the gradient that will arrive has already been multiplied
-    by that derivative (the data-gradient kernel of the consuming layer does it in its epilogue)."""
-    __slots__ = ("mode", "x", "dact", "premultiplied")
+    """Tape entry of a contraction that ran on the bf16 kernels: its input; for a fused activation either the
+    saved derivative (`dact`) or the layer's stored output and the activation's alpha the derivative is recovered
+    from (`yact`, `alpha`; the output is the next layer's taped input, so it costs no memory); and whether the
+    gradient that will arrive has already been multiplied by that derivative (the data-gradient kernel of the
+    consuming layer does it in its epilogue)."""
+    __slots__ = ("mode", "x", "dact", "yact", "alpha", "premultiplied")
 
-    def __init__(self, mode, x, dact):
-        self.mode, self.x, self.dact, self.premultiplied = mode, x, dact, False
+    def __init__(self, mode, x, dact, yact=None, alpha=0.0):
+        self.mode, self.x, self.dact, self.yact, self.alpha, self.premultiplied = mode, x, dact, yact, float(alpha), False
+
+    def has_derivative(self) -> bool:
+        return self.dact is not None or self.yact is not None
 
 
 class Conv2D(_Contraction):

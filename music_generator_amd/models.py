@@ -72,13 +72,23 @@ class WeightedSum(Add):
             g = dy if dy.dtype == torch.bfloat16 else ops.cast_to_bf16(dy)
             da = K.empty(a.shape, dtype=torch.bfloat16) if need[0] else None
             db = K.empty(b.shape, dtype=torch.bfloat16) if need[1] else None
-            # a producer's saved activation derivative is applied here instead of in a multiply launch of its own
-            mul = [None, None]
-            for k, (om, d_) in enumerate(zip(outmuls, (da, db))):
-                if d_ is not None and om is not None and om.dact is not None and not om.premultiplied:
+            # a producer's activation derivative is applied here instead of in a multiply launch of its own: the
+            # saved tensor, or recovered from the producer's stored output, which is this layer's input a / b
+            mul, mal = [None, None], [0.0, 0.0]
+            for k, (om, d_, inp) in enumerate(zip(outmuls, (da, db), (a, b))):
+                if d_ is None or om is None or not om.has_derivative() or om.premultiplied:
+                    continue
+                if om.dact is not None:
                     mul[k] = om.dact
+                elif om.yact is inp:
+                    mal[k] = om.alpha
+            if any(m is not None for m in mul):          # the kernel takes one kind of factor per call
+                mal = [0.0, 0.0]
+            for k, om in enumerate(outmuls):
+                if mul[k] is not None or mal[k] > 0.0:
                     om.premultiplied = True
-            ops.weighted_sum_bf16_bwd(g, a, b, self.alpha.value(), da, db, dalpha, ma=mul[0], mb=mul[1])
+            ops.weighted_sum_bf16_bwd(g, a, b, self.alpha.value(), da, db, dalpha, ma=mul[0], mb=mul[1],
+                                      act_alpha_a=mal[0], act_alpha_b=mal[1])
             return [(da, True) if da is not None else None, (db, True) if db is not None else None]
         mixed = (a.dtype, b.dtype)
         if a.dtype != b.dtype:

@@ -603,7 +603,8 @@ def _conv_bytes_bf16(d: ConvDesc, n_in: int = 1, n_out: int = 1) -> float:
 
 
 def conv_gemm_bf16(d: ConvDesc, x, w, bias, y, dact=None, ymul=None, act_alpha=0.0):
-    """mgx_conv_gemm_bf16: x, y (and dact, ymul) bfloat16; w, bias float32."""
+    """mgx_conv_gemm_bf16: x, y (and dact, ymul) bfloat16; w, bias float32.  ymul with act_alpha > 0: ymul is the
+    stored output of the activation whose derivative multiplies the result (no derivative tensor kept)."""
     xe, ye, we = _conv_sizes(d)
     if x.numel() != xe or y.numel() != ye or w.numel() < we:
         raise MgxError("conv_gemm_bf16: operand sizes do not match the descriptor")
@@ -619,7 +620,8 @@ def conv_gemm_bf16(d: ConvDesc, x, w, bias, y, dact=None, ymul=None, act_alpha=0
                                     _pb(ymul), K.stream_ptr()), "mgx_conv_gemm_bf16")
     if e0 is not None:
         kk = 1 if (d.sh == 2 or d.dkh == 2) else d.kh
-        key = "bconv_kernel<%d,%d,%d>" % (kk, kk, 2 if ymul is not None else (1 if (d.nbias or act_alpha > 0) else 0))
+        key = "bconv_kernel<%d,%d,%d>" % (kk, kk, (4 if act_alpha > 0 else 2) if ymul is not None
+                                          else (1 if (d.nbias or act_alpha > 0) else 0))
         PROFILER.stop(key, _conv_flops(d), e0,
                       _conv_bytes_bf16(d, 1, 1 + (1 if dact is not None else 0) + (1 if ymul is not None else 0)))
 
@@ -785,14 +787,23 @@ def weighted_sum_bf16_fwd(a, b, alpha, y):
 
 
 @_hbm_op("wsum_bf16_bwd")
-def weighted_sum_bf16_bwd(dy, a, b, alpha, da, db, dalpha, ma=None, mb=None):
-    """ma / mb: saved activation derivatives of the producers of a / b; da / db leave multiplied by them."""
+def weighted_sum_bf16_bwd(dy, a, b, alpha, da, db, dalpha, ma=None, mb=None, act_alpha_a=0.0, act_alpha_b=0.0):
+    """ma / mb: saved activation derivatives of the producers of a / b; da / db leave multiplied by them.
+    act_alpha_a / act_alpha_b (instead of ma / mb): a / b are the stored outputs of the activations that produced
+    them and the derivatives are recovered from them."""
     n = dy.numel()
     for t in (a, b, da, db, ma, mb):
         if t is not None and t.numel() != n:
             raise MgxError("weighted_sum_bf16_bwd: size mismatch")
     lib = _lib()
     ws = K.workspace(lib.mgx_reduce_workspace())
+    if act_alpha_a > 0.0 or act_alpha_b > 0.0:
+        if ma is not None or mb is not None:
+            raise MgxError("weighted_sum_bf16_bwd: stored derivatives and recovered ones exclude each other")
+        check(lib.mgx_weighted_sum_bf16_bwd_act(_pb(dy), _pb(a), _pb(b), _p(alpha), _pb(da), _pb(db), _p(dalpha),
+                                                float(act_alpha_a), float(act_alpha_b), ws.data_ptr(), ws.numel(), n,
+                                                K.stream_ptr()), "mgx_weighted_sum_bf16_bwd_act")
+        return
     check(lib.mgx_weighted_sum_bf16_bwd_mul(_pb(dy), _pb(a), _pb(b), _p(alpha), _pb(da), _pb(db), _p(dalpha), _pb(ma),
                                             _pb(mb), ws.data_ptr(), ws.numel(), n, K.stream_ptr()),
           "mgx_weighted_sum_bf16_bwd_mul")
@@ -868,6 +879,19 @@ def mul_bf16(a, b):
     f32 = a.dtype == torch.float32
     check(_lib().mgx_mul_bf16(_p(a) if f32 else _pb(a), int(f32), _pb(b), _pb(out), b.numel(), K.stream_ptr()),
           "mgx_mul_bf16")
+    return out
+
+
+@_hbm_op("mul_bf16")
+def mul_dact_bf16(a, y, act_alpha):
+    """bf16(a * f'(y)): a bfloat16 or float32; y the stored bfloat16 output of tanh(v) + v/alpha, from which the
+    derivative is recovered."""
+    if a.numel() != y.numel():
+        raise MgxError("mul_dact_bf16: size mismatch")
+    out = torch.empty(y.shape, dtype=torch.bfloat16, device=y.device)
+    f32 = a.dtype == torch.float32
+    check(_lib().mgx_mul_dact_bf16(_p(a) if f32 else _pb(a), int(f32), _pb(y), float(act_alpha), _pb(out), y.numel(),
+                                   K.stream_ptr()), "mgx_mul_dact_bf16")
     return out
 
 

@@ -4,8 +4,11 @@ arithmetic in between.
 
 The device path (music_generator_amd with backend.set_precision("bfloat16")) keeps the 32 / 128-channel
 activations of the discriminator's grow blocks (trainer/models.py:256-281) at 8 rows and more in bf16:
-  * the output of every Conv2D + SoftRectifier there is rounded to bf16, and so is the saved derivative
-    1 - tanh^2 + 1/alpha;
+  * the output y of every Conv2D + SoftRectifier there is rounded to bf16; the backward pass takes the
+    activation's derivative from that STORED output, max(1 + 1/alpha - y^2, 1/alpha) (SAVE_DERIVATIVE = False,
+    the device's default: no derivative tensor is kept), or, with SAVE_DERIVATIVE = True
+    (backend.BF16_SAVE_DERIVATIVE on the device), from a second tensor holding 1 - tanh^2 + 1/alpha rounded
+    to bf16;
   * the weights of those convolutions are rounded to bf16 as they enter the matrix unit (the from-audio
     convolution with its 2 float32 input channels runs on float32 weights);
   * the gradient with respect to a pre-activation, dY (.) f', is rounded to bf16;
@@ -21,6 +24,7 @@ import torch
 from . import ref_step as R
 
 MIN_ROWS = 8
+SAVE_DERIVATIVE = False
 
 
 def _round(t):
@@ -62,14 +66,19 @@ class _RoundGrad(torch.autograd.Function):
 
 
 class _ActStored(torch.autograd.Function):
-    """tanh(x) + x/alpha with the output and the saved derivative stored as bf16 and the incoming
-    gradient multiplied by the stored derivative, the product stored as bf16."""
+    """tanh(x) + x/alpha with the output stored as bf16 and the incoming gradient multiplied by the derivative the
+    device uses (recovered from the stored output, or a derivative stored as bf16), the product stored as bf16."""
 
     @staticmethod
     def forward(ctx, pre, alpha):
         t = torch.tanh(pre)
-        ctx.save_for_backward(_round(1.0 - t * t + 1.0 / alpha))
-        return _round(t + pre / alpha)
+        y = _round(t + pre / alpha)
+        if SAVE_DERIVATIVE:
+            d = _round(1.0 - t * t + 1.0 / alpha)
+        else:
+            d = torch.clamp(1.0 + 1.0 / alpha - y * y, min=1.0 / alpha)
+        ctx.save_for_backward(d)
+        return y
 
     @staticmethod
     def backward(ctx, g):

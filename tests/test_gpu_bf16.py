@@ -119,6 +119,14 @@ def test_bf16_conv_forward_dgrad_wgrad(case):
     _close_b(dx, gx.numpy() * mul, "data-gradient x multiplier")
     ops.conv_gemm_bf16(dd, dyd, kd, None, dx)
     _close_b(dx, gx.numpy(), "data-gradient")
+    # ... and with the factor recovered from a stored activation OUTPUT (no derivative tensor): values of tanh(v) +
+    # v/alpha as bf16, some of them rounded up past 1, where the recovered derivative is held at 1/alpha
+    act_out = _bf(np.tanh(3.0 * mul - 1.5) + (3.0 * mul - 1.5) / alpha)
+    act_out.reshape(-1)[::97] = _bf(np.float32(1.0 + 2.0 ** -7))
+    ops.conv_gemm_bf16(dd, dyd, kd, None, dx, ymul=_dev_b(act_out), act_alpha=alpha)
+    rec = np.maximum(1.0 + 1.0 / alpha - act_out.astype(np.float64) ** 2, 1.0 / alpha)
+    assert rec.min() == 1.0 / alpha
+    _close_b(dx, gx.numpy() * rec, "data-gradient x recovered derivative")
 
     # weight / bias gradient (added to what the buffers hold)
     dw = torch.full(layer.kernel.shape, 0.5, dtype=torch.float32, device="cuda").view(-1)
@@ -180,6 +188,19 @@ def test_bf16_weighted_sum(alpha):
     _close_b(da, (1 - alpha) * dy.astype(np.float64), "da")
     _close_b(db, alpha * dy.astype(np.float64), "db")
     _close_f(dal, np.array([(dy.astype(np.float64) * (b.astype(np.float64) - a)).sum()]), "dalpha", 1e-5)
+    # the same with the producers' activation derivatives recovered from a and b (their stored outputs)
+    ya, yb = _bf(np.tanh(a)), _bf(np.tanh(b) + b / 11000.0)
+    yad, ybd = _dev_b(ya), _dev_b(yb)
+    dal2 = torch.zeros((1,), dtype=torch.float32, device="cuda")
+    ops.weighted_sum_bf16_bwd(dyd, yad, ybd, al, da, db, dal2, act_alpha_a=40000.0, act_alpha_b=11000.0)
+    fa = np.maximum(1 + 1 / 40000.0 - ya.astype(np.float64) ** 2, 1 / 40000.0)
+    fb = np.maximum(1 + 1 / 11000.0 - yb.astype(np.float64) ** 2, 1 / 11000.0)
+    _close_b(da, _bf((1 - alpha) * dy).astype(np.float64) * fa, "da x recovered derivative")
+    _close_b(db, _bf(alpha * dy).astype(np.float64) * fb, "db x recovered derivative")
+    _close_f(dal2, np.array([(dy.astype(np.float64) * (yb.astype(np.float64) - ya)).sum()]), "dalpha", 1e-5)
+    da0 = torch.empty_like(da)
+    ops.weighted_sum_bf16_bwd(dyd, yad, ybd, al, da0, None, None)
+    assert torch.equal(da, ops.mul_dact_bf16(da0, yad, 40000.0))      # rounded where a multiply launch of its own rounds
 
 
 def test_bf16_casts_round_trip():
@@ -379,6 +400,62 @@ def test_bf16_discriminator_vs_plain_oracle(stage, twin):
     for k, err in errs.items():
         bound = 3e-1 if k.endswith("/alpha") else (1.2e-1 if k.endswith("/bias") else 8e-2)
         assert err <= bound, "%s: rel-L2 %.3e" % (k, err)
+
+
+@pytest.mark.parametrize("stage,twin", [(2, 1)])
+def test_bf16_derivative_recovered_from_output_against_stored_derivative(stage, twin):
+    """backend.BF16_SAVE_DERIVATIVE: the default (False) keeps no derivative tensor and recovers 1 - tanh^2 + 1/alpha
+    from the stored bf16 output; True stores it as a second bf16 tensor.  Same forward bit for bit; the gradients
+    of the two settings differ by the rounding of y that enters 1 - y^2 (absolute 2 |y| 2^-9 per element against
+    the 2^-9 relative of a stored derivative).  Stated bound between the two settings, and of each against the
+    oracle that emulates it: relative L2 <= 2e-2 x blocks (3e-2 x blocks for bias gradients, 3e-1 for alpha), the
+    bound of test_bf16_grow_blocks_match_oracle."""
+    from oracle import bf16_emulation as E
+    from music_generator_amd import backend as K
+    real, _ = R.synthetic_inputs(stage, 4, seed=0)
+    rng = np.random.default_rng(3)
+    dy = rng.standard_normal((4, 4, 750, 128)).astype(np.float32)
+    runs = {}
+    for keep in (False, True):
+        d, g, comp, W = _build(stage + 1)
+        full = d[stage][twin]
+        for layer in full.layers:
+            if isinstance(layer, M.WeightedSum):
+                M.backend.set_value(layer.alpha, 0.37)
+        model = _blocks_model(full)
+        M.backend.set_precision("bfloat16")
+        K.BF16_SAVE_DERIVATIVE = keep
+        try:
+            torch.cuda.reset_peak_memory_stats()
+            base = torch.cuda.memory_allocated()
+            y, tape = model.forward(torch.from_numpy(real).cuda(), save=True)
+            held = torch.cuda.memory_allocated() - base
+            model.bind_grads().zero_()
+            dx = model.backward(tape, torch.from_numpy(dy).cuda(), need_input_grad=True)
+            torch.cuda.synchronize()
+        finally:
+            M.backend.set_precision("float32")
+            K.BF16_SAVE_DERIVATIVE = False
+        grads = {v.name: v.grad.cpu().numpy().reshape(v.shape).copy() for v in model.trainable_variables}
+        E.SAVE_DERIVATIVE = keep
+        try:
+            yo, dxo, go = _oracle_blocks(W, stage + 1, stage, bool(twin), real, 0.37, dy, True)
+        finally:
+            E.SAVE_DERIVATIVE = False
+        runs[keep] = (y.float().cpu().numpy(), dx.float().cpu().numpy(), grads, held)
+        tol = 2e-2 * stage
+        assert rel_l2(runs[keep][0], yo) <= tol and rel_l2(runs[keep][1], dxo) <= tol
+        for k in go:
+            bound = 3e-1 if k.endswith("/alpha") else (1.5 * tol if k.endswith("/bias") else tol)
+            assert rel_l2(grads[k], go[k]) <= bound, "%s (stored derivative: %s): %.3e" % (k, keep, rel_l2(grads[k], go[k]))
+    (y0, dx0, g0, held0), (y1, dx1, g1, held1) = runs[False], runs[True]
+    assert np.array_equal(y0, y1)
+    worst = max((rel_l2(g0[k], g1[k]), k) for k in g0 if not k.endswith("/alpha"))
+    print("recovered against stored derivative: dx", rel_l2(dx0, dx1), "worst weight gradient", worst,
+          "tape bytes", held0, "against", held1)
+    tol = 2e-2 * stage
+    assert rel_l2(dx0, dx1) <= tol and worst[0] <= 1.5 * tol
+    assert held0 <= 0.62 * held1          # the tape of the taped forward: outputs only against outputs + derivatives
 
 
 @pytest.mark.parametrize("name", ["s1_straight_n4", "s2_fade_a037_n4"])
