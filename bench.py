@@ -188,18 +188,36 @@ def build_gan(M, stage, fade, precision, micro_batch=None, side_budget_gib=0.0):
     return gan
 
 
+HBM_PEAK_GBPS = 8000.0
+
+
 def roofline_of(summ, steps, ms_per_step, peak, traffic=None):
+    """The kernel family with the largest share of the timed region, priced against the roof that bounds it: the
+    dense MFMA peak of its dtype, or, when its algorithmic FLOPs per byte lie below the ridge (peak / 8 TB/s), the
+    HBM peak; the other roof's figures ride along."""
     contr = {k: v for k, v in summ.items() if v[2] > 0.0}
     key, (launches, ms, flops, nbytes) = max(contr.items(), key=lambda kv: kv[1][1])
     achieved = flops / (ms * 1e-3) / 1e12
-    return key, {"bound": "mfma", "kernel": key, "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
-                 "frac": round(achieved / peak, 4), "traffic": traffic,
+    gbps = nbytes / ms / 1e6
+    ridge = peak * 1e12 / (HBM_PEAK_GBPS * 1e9)
+    intensity = flops / nbytes if nbytes else float("inf")
+    if intensity < ridge:
+        head = {"bound": "hbm", "kernel": key, "achieved": round(gbps, 1), "peak": HBM_PEAK_GBPS, "unit": "GB/s",
+                "frac": round(gbps / HBM_PEAK_GBPS, 4), "traffic": traffic,
+                "algorithmic_flop_per_byte": round(intensity, 1), "ridge_flop_per_byte": round(ridge, 1),
+                "mfma_TFLOPs": round(achieved, 2), "mfma_peak_TFLOPs": peak, "mfma_frac": round(achieved / peak, 4)}
+    else:
+        head = {"bound": "mfma", "kernel": key, "achieved": round(achieved, 2), "peak": peak, "unit": "TFLOP/s",
+                "frac": round(achieved / peak, 4), "traffic": traffic,
+                "algorithmic_flop_per_byte": round(intensity, 1), "ridge_flop_per_byte": round(ridge, 1)}
+    head.update({
                  "algorithmic_gflop_per_launch": round(flops / launches / 1e9, 2),
                  "algorithmic_bytes_per_launch": round(nbytes / launches),
                  "algorithmic_GBps": round(nbytes / ms / 1e6, 1),
                  "launches": launches, "avg_launch_ms": round(ms / launches, 4),
                  "share_of_step_time": round(ms / steps / ms_per_step, 3),
-                 "all_contractions_share_of_step_time": round(sum(v[1] for v in contr.values()) / steps / ms_per_step, 3)}
+                 "all_contractions_share_of_step_time": round(sum(v[1] for v in contr.values()) / steps / ms_per_step, 3)})
+    return key, head
 
 
 def progress(msg):
@@ -604,7 +622,7 @@ def main():
         if (stage, fade, args.batch) == (3, True, 64):
             roof["mfma_busy_frac_sq_counters"] = measured_mfma_busy(key, "r2_c2bf16" if args.precision == "bfloat16"
                                                                     else "r2_c2")
-        if key.startswith("wino3_"):
+        if key.startswith("wino3_") and roof["bound"] == "mfma":
             # the kernel's algorithm is Winograd F(2x2,3x3): `achieved` counts the multiply-adds it executes
             # (16 per 2x2 patch and channel pair); the same launches as a rate of direct-convolution FLOPs:
             roof["direct_convolution_equivalent_tflops"] = round(roof["achieved"] / ops.WINOGRAD_FLOP_FRACTION, 2)

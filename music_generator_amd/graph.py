@@ -154,6 +154,12 @@ class FusedGroup:
     side_budget_bytes = None
     # without a bound the taped forward checks the free memory once its tape exceeds this many bytes
     auto_budget_from_bytes = 4 << 30
+    # bytes the caller knows it will allocate between this taped forward and its backward (the train step
+    # announces the discriminator tape that follows the generator's forward in the generator update): the
+    # automatic bound counts them as taken
+    reserve_bytes = 0
+    # (tape bytes, bound chosen or None) of the automatic decisions taken so far, newest last (diagnostics)
+    decisions: list = []
 
     def __init__(self, input: KTensor, output: KTensor, nodes: List[Node], optional_nodes: List[Node], run):
         self.input, self.output, self.nodes, self.optional_nodes, self.run = input, output, nodes, optional_nodes, run
@@ -334,6 +340,24 @@ class Model:
 
     def count_params(self) -> int:
         return sum(v.size for v in self.trainable_variables)
+
+    def tape_bytes_estimate(self, n: int) -> int:
+        """Bytes a taped forward of `n` samples keeps for its backward, from the plan's symbolic shapes: every
+        step's output (the next step's saved input), in bf16 where the bf16 kernels store it, plus the saved
+        activation derivative where one is kept (float32 convolutions; bf16 ones only with
+        backend.BF16_SAVE_DERIVATIVE).  An estimate for memory planning, not an accounting."""
+        total = 0
+        bf = K.bf16_enabled()
+        for op in self._plan:
+            shape = op.output.shape
+            elems = 1
+            for d in shape[1:]:
+                elems *= int(d)
+            conv = getattr(op.node.layer, "fusable_activation", False) and len(shape) == 4
+            half = bf and conv and shape[1] >= K.BF16_MIN_ROWS and shape[-1] in (32, 128)
+            copies = 2 if (op.act_node is not None and (not half or K.BF16_SAVE_DERIVATIVE)) else 1
+            total += elems * (2 if half else 4) * copies
+        return int(total) * int(n)
 
     def get_layer(self, name):
         for l in self.layers:

@@ -358,12 +358,21 @@ def _register_fused_block(block_end, upsampling, for_sum_layer):
         budget = FusedGroup.side_budget_bytes
         side_bytes = (2 if bf else 4) * side
         if budget is None and side_bytes > FusedGroup.auto_budget_from_bytes:
-            # no bound given: keep the tape only if it and the gradient side buffer of the same size the backward
-            # will want leave room (the full-resolution stage at the reference's batch of 2 needs 2 x 94 GiB in
-            # float32); otherwise bound both to 1/16 of the device memory and re-compute
-            avail, total = K.available_bytes()
-            if 2 * side_bytes > 0.6 * avail:
-                budget = max(total // 16, 1 << 20)
+            # no bound given: keep the tape only if it, the gradient side buffer of the same size the backward
+            # will want and what the caller announced it will allocate in between (FusedGroup.reserve_bytes: the
+            # discriminator's tape in the generator update) leave room (the full-resolution stage at the
+            # reference's batch of 2 needs 2 x 94 GiB in float32); otherwise bound both to 1/16 of the device
+            # memory and re-compute.  Decided once per shape: a later call (the capture of a HIP graph after the
+            # eager warm-up, say) must take the path whose scratch sizes the first one established.
+            key = ("bound", n, hl, wl, bf)
+            if key not in state:
+                avail, total = K.available_bytes()
+                need = 2 * side_bytes + FusedGroup.reserve_bytes
+                state[key] = max(total // 16, 1 << 20) if need > (0.6 if not FusedGroup.reserve_bytes else 0.75) * avail \
+                    else None
+                FusedGroup.decisions.append((side_bytes, state[key]))
+                del FusedGroup.decisions[:-64]
+            budget = state[key]
         if budget is not None and side_bytes > budget:
             return run(x), (None, x, (n, hl, wl), bf, budget)
         y = K.empty((n, 2 * hl, 2 * wl, 2))
@@ -1100,7 +1109,13 @@ class WGAN:
             if early:
                 gen, tape_g, early_gen, early_tape = early_gen, early_tape, None, None
             else:
-                gen, tape_g = G.forward(zb, save=chunk is None)
+                # what follows the generator's taped forward before its backward frees anything: the generated
+                # batch, the discriminator's tape of it and the gradient that comes back
+                FusedGroup.reserve_bytes = D.tape_bytes_estimate(nb) + 2 * rb.numel() * 4
+                try:
+                    gen, tape_g = G.forward(zb, save=chunk is None)
+                finally:
+                    FusedGroup.reserve_bytes = 0
             gen_logits, tape_d = D.forward(gen, save=True)
             del gen
             dgen = D.backward(tape_d, self._ones(nb), need_input_grad=True, need_weight_grads=False)

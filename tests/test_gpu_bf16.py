@@ -655,6 +655,40 @@ def test_bf16_full_resolution_step_properties(bf16_precision):
         FusedGroup.side_budget_bytes = None
 
 
+def test_bf16_generator_tape_bound_is_chosen_without_any_setting(bf16_precision):
+    """Stage 5 (128 x 24000), batch 16, bf16, whole batch, no micro-batch and no FusedGroup.side_budget_bytes: the
+    generator's tape (94 GiB for the top block) and its gradient buffer would fit the memory that is free at the
+    generator's forward, but not beside the discriminator tape that follows in the generator update.  The train
+    step announces that tape (Model.tape_bytes_estimate), so the automatic bound is chosen for the top block and
+    the step runs without the allocator having to give memory back and ask again (num_alloc_retries stays 0 over
+    the second step)."""
+    from music_generator_amd.graph import FusedGroup
+    stage, n = 5, 16
+    FusedGroup.decisions.clear()
+    gan = _fresh_gan(stage, None)
+    assert FusedGroup.side_budget_bytes is None
+    est = gan.discriminator.tape_bytes_estimate(n)
+    assert 40e9 < est < 120e9, est                     # 128 x 24000 x 896 B a position and sample, plus the lower blocks
+    gen = torch.Generator(device="cuda")
+    gen.manual_seed(4)
+    real = torch.rand((n, 4 << stage, 750 << stage, 2), device="cuda", generator=gen) * 2 - 1
+    m = {k: float(v) for k, v in gan.train_step(real).items()}
+    assert all(np.isfinite(v) for v in m.values()), m
+    top = max(FusedGroup.decisions, key=lambda d: d[0])
+    assert top[0] > 60e9 and top[1] is not None and top[1] <= 20 * 2 ** 30, FusedGroup.decisions
+    retries = torch.cuda.memory_stats()["num_alloc_retries"]
+    torch.cuda.synchronize()
+    import time
+    t0 = time.perf_counter()
+    m = {k: float(v) for k, v in gan.train_step(real).items()}
+    print("D tape estimate %.1f GB, decisions %s, second step %.2f s, peak %.1f GiB" % (
+        est / 1e9, FusedGroup.decisions, time.perf_counter() - t0, torch.cuda.max_memory_allocated() / 2 ** 30))
+    assert all(np.isfinite(v) for v in m.values()), m
+    assert torch.cuda.memory_stats()["num_alloc_retries"] == retries
+    del gan, real
+    torch.cuda.empty_cache()
+
+
 def test_bf16_full_resolution_step_at_batch_256(bf16_precision):
     """The full-resolution bench configuration itself: stage 6 (256 x 48000) fade-in step, batch 256 in 64
     micro-batches of one MinibatchStdDev group, generator tape bounded to 8 GiB, bf16.  Properties that do
