@@ -459,6 +459,20 @@ int mgx_gblock_dgrad_bf16(const mgx_gblock_weights* w, void* packt, const float*
                           int64_t nimg, int hl, int wl, int64_t pos0, int64_t npos, void* stream);
 int mgx_gblock_wgrad_bf16(const void* act, const void* delta, const mgx_gblock_grads* g, void* workspace,
                           int64_t workspace_bytes, int64_t npos, void* stream);
+/* The same gradients without four of the tape's tensors: the output of the six Conv2DTranspose(64) and of Dense(256)
+ * (models.py:377-378, 386) and the gradients that arrive at them make up 5120 of the 8138 rows of a 32-position tile
+ * of the side buffers, and each is one linear layer away from rows the tape keeps.  mgx_gblock_wgrad_bf16_lean
+ * recomputes them tile by tile from those rows and the block's weights `w` (the values the forward ran with) and
+ * never reads their rows of `act` / `delta`; it accepts buffers written by either pair of entry points.
+ * mgx_gblock_fwd_bf16_lean / mgx_gblock_dgrad_bf16_lean are mgx_gblock_fwd_bf16 / _dgrad_bf16 that leave those rows
+ * of `act` (required here) / `delta` unwritten: the buffers keep their size and row map, the backward moves 37 % of
+ * the bytes.  Same workspace size (mgx_gblock_wgrad_workspace_n covers both). */
+int mgx_gblock_fwd_bf16_lean(const mgx_gblock_weights* w, void* packb, const float* x, float* y, void* act, int64_t nimg,
+                             int hl, int wl, int64_t pos0, int64_t npos, void* stream);
+int mgx_gblock_dgrad_bf16_lean(const mgx_gblock_weights* w, void* packt, const float* dy, void* delta, float* dx,
+                               int64_t nimg, int hl, int wl, int64_t pos0, int64_t npos, void* stream);
+int mgx_gblock_wgrad_bf16_lean(const mgx_gblock_weights* w, const void* act, const void* delta, const mgx_gblock_grads* g,
+                               void* workspace, int64_t workspace_bytes, int64_t npos, void* stream);
 
 /* out = a (.) b over n elements (n a multiple of 8): b and out bf16, a bf16 or float32 (a_is_f32): the
  * product dY (.) f' of tf.GradientTape through a SoftRectifier (models.py:205-206) where the kernel that

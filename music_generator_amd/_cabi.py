@@ -146,6 +146,9 @@ PROTOTYPES = {
     "mgx_gblock_fwd_bf16": (_I, [C.POINTER(GBlockWeights), _P, _P, _P, _P, _I64, _I, _I, _I64, _I64, _P]),
     "mgx_gblock_dgrad_bf16": (_I, [C.POINTER(GBlockWeights), _P, _P, _P, _P, _I64, _I, _I, _I64, _I64, _P]),
     "mgx_gblock_wgrad_bf16": (_I, [_P, _P, C.POINTER(GBlockWeights), _P, _I64, _I64, _P]),
+    "mgx_gblock_fwd_bf16_lean": (_I, [C.POINTER(GBlockWeights), _P, _P, _P, _P, _I64, _I, _I, _I64, _I64, _P]),
+    "mgx_gblock_dgrad_bf16_lean": (_I, [C.POINTER(GBlockWeights), _P, _P, _P, _P, _I64, _I, _I, _I64, _I64, _P]),
+    "mgx_gblock_wgrad_bf16_lean": (_I, [C.POINTER(GBlockWeights), _P, _P, C.POINTER(GBlockWeights), _P, _I64, _I64, _P]),
     "mgx_mul_bf16": (_I, [_P, _I, _P, _P, _I64, _P]),
     "mgx_mul_dact_bf16": (_I, [_P, _I, _P, _F, _P, _I64, _P]),
     "mgx_cast_f32_to_bf16": (_I, [_P, _P, _I64, _P]),

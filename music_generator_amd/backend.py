@@ -132,6 +132,10 @@ BF16_MIN_ROWS = 8
 # traffic in every taped forward.  True: the derivative is written as a bf16 tensor of its own by the forward
 # epilogue (one more rounding-exact value per element, twice the tape).
 BF16_SAVE_DERIVATIVE = False
+# bf16 generator grow blocks: leave the outputs of the Conv2DTranspose(64) / Dense(256) layers and the gradients
+# arriving at them off the tape (5120 of its 8138 rows per 32 positions); the weight-gradient kernels recompute
+# them from the neighbouring rows.  False: every tensor on the tape, every weight gradient read from it.
+GBLOCK_LEAN_TAPE = True
 
 
 def set_precision(name: str):

@@ -233,7 +233,7 @@ template <bool SAVE, int NW>
 __global__ __launch_bounds__(64 * NW, 1) void gblock_fwd_bf16_kernel(const unsigned char* __restrict__ packb,
                                                                  const float* __restrict__ x, float* __restrict__ y,
                                                                  bf16_t* __restrict__ act, long pos0, long npix, int hl,
-                                                                 int wl, long ntiles) {
+                                                                 int wl, long ntiles, int lean) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -328,7 +328,8 @@ __global__ __launch_bounds__(64 * NW, 1) void gblock_fwd_bf16_kernel(const unsig
                         for (int ks = 0; ks < 2; ++ks)
                             o3 = mfma_bf16(frag(wb, FB_K2 + (b * 2 + ot) * 2 + ks, lane), o2b.k[ks], o3);
                         o3b[ot] = to_b(o3);
-                        if (SAVE) save_b<2>(abr, GB_O3 + (A * 2 + b) * 64 + ot * 32, o3b[ot], r, h, tl);
+                        // lean tape: the weight gradients recompute this tensor from o2 (gblock_lean.hip)
+                        if (SAVE && !lean) save_b<2>(abr, GB_O3 + (A * 2 + b) * 64 + ot * 32, o3b[ot], r, h, tl);
                     }
                     // the four output tiles innermost: an MFMA that continues the accumulator of the one before it
                     // issues ~5 % later than one on another accumulator (measured: 35.4 against 34.0 cycles); every
@@ -386,7 +387,7 @@ __global__ __launch_bounds__(64 * NW, 1) void gblock_fwd_bf16_kernel(const unsig
 #pragma unroll
                             for (int ks = 0; ks < 2; ++ks) T1 = mfma_bf16(frag(wc, it * 2 + ks, lane), Sb[b][it].k[ks], T1);
                         const BTile T1b = to_b(T1);
-                        if (SAVE) save_b<2>(at, GB_T1 + (A * 2 + b) * 256 + c * 32, T1b, r, h, tl);
+                        if (SAVE && !lean) save_b<2>(at, GB_T1 + (A * 2 + b) * 256 + c * 32, T1b, r, h, tl);
 #pragma unroll
                         for (int ot = 0; ot < 2; ++ot)
 #pragma unroll
@@ -503,7 +504,8 @@ __device__ __forceinline__ void zero_tile(f32x16& t) {
 __global__ __launch_bounds__(256, 1) void gblock_dgrad_bf16_kernel(const unsigned char* __restrict__ packt,
                                                                    const float* __restrict__ dy,
                                                                    bf16_t* __restrict__ delta, float* __restrict__ dx,
-                                                                   long pos0, long npix, int hl, int wl, long ntiles) {
+                                                                   long pos0, long npix, int hl, int wl, long ntiles,
+                                                                   int lean) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -584,7 +586,7 @@ __global__ __launch_bounds__(256, 1) void gblock_dgrad_bf16_kernel(const unsigne
 #pragma unroll
                             for (int ks = 0; ks < 2; ++ks) dT1 = mfma_bf16(frag(wc, it * 2 + ks, lane), dT2b[b][it].k[ks], dT1);
                         const BTile t1 = to_b(dT1);
-                        save_b<2>(dt, GB_T1 + (a * 2 + b) * 256 + c * 32, t1, r, h, tl);
+                        if (!lean) save_b<2>(dt, GB_T1 + (a * 2 + b) * 256 + c * 32, t1, r, h, tl);
 #pragma unroll
                         for (int ot = 0; ot < 4; ++ot)
 #pragma unroll
@@ -625,7 +627,7 @@ __global__ __launch_bounds__(256, 1) void gblock_dgrad_bf16_kernel(const unsigne
                             for (int ks = 0; ks < 2; ++ks)
                                 do3 = mfma_bf16(frag(wb, PB_D2 + (it * 4 + ot) * 2 + ks, lane), dSb[b][ot].k[ks], do3);
                         do3b[it] = to_b(do3);
-                        save_b<2>(dbr, GB_O3 + (a * 2 + b) * 64 + it * 32, do3b[it], r, h, tl);
+                        if (!lean) save_b<2>(dbr, GB_O3 + (a * 2 + b) * 64 + it * 32, do3b[it], r, h, tl);
                     }
 #pragma unroll
                     for (int it = 0; it < 2; ++it)
@@ -693,8 +695,8 @@ static int fwd_waves() {
     return nw;
 }
 
-extern "C" int mgx_gblock_fwd_bf16(const mgx_gblock_weights* wp, void* packb, const float* x, float* y, void* act,
-                                   int64_t nimg, int hl, int wl, int64_t pos0, int64_t npos, void* stream) {
+static int gblock_fwd_bf16_any(const mgx_gblock_weights* wp, void* packb, const float* x, float* y, void* act,
+                               int64_t nimg, int hl, int wl, int64_t pos0, int64_t npos, void* stream, int lean) {
     if (!wp || !packb || !x || (!y && !act) || nimg <= 0 || hl <= 0 || wl <= 0) return MGX_ERR_ARG;
     const long npix = (long)nimg * hl * wl;
     if (pos0 < 0 || pos0 >= npix || (pos0 & 127)) return MGX_ERR_ARG;
@@ -711,7 +713,7 @@ extern "C" int mgx_gblock_fwd_bf16(const mgx_gblock_weights* wp, void* packb, co
                                 LDS_BYTES) != hipSuccess)
             return MGX_ERR_LAUNCH;
         hipLaunchKernelGGL((gblock_fwd_bf16_kernel<true, 4>), dim3(grid), dim3(256), LDS_BYTES, st,
-                           (const unsigned char*)packb, x, y, (bf16_t*)act, (long)pos0, end, hl, wl, ntiles);
+                           (const unsigned char*)packb, x, y, (bf16_t*)act, (long)pos0, end, hl, wl, ntiles, lean);
     } else if (fwd_waves() == 8) {
         const long nt8 = (end - pos0 + 255) / 256;
         const unsigned grid8 = (unsigned)(nt8 < 256 ? nt8 : 256);
@@ -719,19 +721,30 @@ extern "C" int mgx_gblock_fwd_bf16(const mgx_gblock_weights* wp, void* packb, co
                                 LDS_BYTES) != hipSuccess)
             return MGX_ERR_LAUNCH;
         hipLaunchKernelGGL((gblock_fwd_bf16_kernel<false, 8>), dim3(grid8), dim3(512), LDS_BYTES, st,
-                           (const unsigned char*)packb, x, y, (bf16_t*)nullptr, (long)pos0, end, hl, wl, nt8);
+                           (const unsigned char*)packb, x, y, (bf16_t*)nullptr, (long)pos0, end, hl, wl, nt8, 0);
     } else {
         if (hipFuncSetAttribute((const void*)gblock_fwd_bf16_kernel<false, 4>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 LDS_BYTES) != hipSuccess)
             return MGX_ERR_LAUNCH;
         hipLaunchKernelGGL((gblock_fwd_bf16_kernel<false, 4>), dim3(grid), dim3(256), LDS_BYTES, st,
-                           (const unsigned char*)packb, x, y, (bf16_t*)nullptr, (long)pos0, end, hl, wl, ntiles);
+                           (const unsigned char*)packb, x, y, (bf16_t*)nullptr, (long)pos0, end, hl, wl, ntiles, 0);
     }
     return mgx_launch_status();
 }
 
-extern "C" int mgx_gblock_dgrad_bf16(const mgx_gblock_weights* wp, void* packt, const float* dy, void* delta, float* dx,
-                                     int64_t nimg, int hl, int wl, int64_t pos0, int64_t npos, void* stream) {
+extern "C" int mgx_gblock_fwd_bf16(const mgx_gblock_weights* wp, void* packb, const float* x, float* y, void* act,
+                                   int64_t nimg, int hl, int wl, int64_t pos0, int64_t npos, void* stream) {
+    return gblock_fwd_bf16_any(wp, packb, x, y, act, nimg, hl, wl, pos0, npos, stream, 0);
+}
+
+extern "C" int mgx_gblock_fwd_bf16_lean(const mgx_gblock_weights* wp, void* packb, const float* x, float* y, void* act,
+                                        int64_t nimg, int hl, int wl, int64_t pos0, int64_t npos, void* stream) {
+    if (!act) return MGX_ERR_ARG;
+    return gblock_fwd_bf16_any(wp, packb, x, y, act, nimg, hl, wl, pos0, npos, stream, 1);
+}
+
+static int gblock_dgrad_bf16_any(const mgx_gblock_weights* wp, void* packt, const float* dy, void* delta, float* dx,
+                                 int64_t nimg, int hl, int wl, int64_t pos0, int64_t npos, void* stream, int lean) {
     if (!wp || !packt || !dy || !delta || !dx || nimg <= 0 || hl <= 0 || wl <= 0) return MGX_ERR_ARG;
     const long npix = (long)nimg * hl * wl;
     if (pos0 < 0 || pos0 >= npix || (pos0 & 127)) return MGX_ERR_ARG;
@@ -747,6 +760,16 @@ extern "C" int mgx_gblock_dgrad_bf16(const mgx_gblock_weights* wp, void* packt, 
         return MGX_ERR_LAUNCH;
     const unsigned grid = (unsigned)(ntiles < 256 ? ntiles : 256);
     hipLaunchKernelGGL(gblock_dgrad_bf16_kernel, dim3(grid), dim3(256), TLDS_BYTES, st, (const unsigned char*)packt, dy,
-                       (bf16_t*)delta, dx, (long)pos0, end, hl, wl, ntiles);
+                       (bf16_t*)delta, dx, (long)pos0, end, hl, wl, ntiles, lean);
     return mgx_launch_status();
+}
+
+extern "C" int mgx_gblock_dgrad_bf16(const mgx_gblock_weights* wp, void* packt, const float* dy, void* delta, float* dx,
+                                     int64_t nimg, int hl, int wl, int64_t pos0, int64_t npos, void* stream) {
+    return gblock_dgrad_bf16_any(wp, packt, dy, delta, dx, nimg, hl, wl, pos0, npos, stream, 0);
+}
+
+extern "C" int mgx_gblock_dgrad_bf16_lean(const mgx_gblock_weights* wp, void* packt, const float* dy, void* delta, float* dx,
+                                          int64_t nimg, int hl, int wl, int64_t pos0, int64_t npos, void* stream) {
+    return gblock_dgrad_bf16_any(wp, packt, dy, delta, dx, nimg, hl, wl, pos0, npos, stream, 1);
 }

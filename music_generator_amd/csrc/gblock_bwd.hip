@@ -15,6 +15,7 @@
 #include "bf16.h"
 #include "gblock_frag.h"
 #include "gblock_rows.h"
+#include "gblock_jobs.h"
 #include "../../include/mgx.h"
 
 #include <type_traits>
@@ -225,20 +226,6 @@ __global__ __launch_bounds__(256, 1) void gblock_dgrad_kernel(const float* __res
 // ------------------------------------------------------------------------------------------
 // weight gradients
 // ------------------------------------------------------------------------------------------
-struct GJob {
-    int rowA, rowB;          // first activation / gradient row of sub-position term 0
-    int nsub;                // terms contracted besides the positions (sub-positions sharing the weight)
-    int strideA, strideB;    // row stride between terms
-    int bias;                // 1: also sum the gradient operand over positions
-    int nsplit;              // waves sharing the job (slabs)
-    int pad;
-    long ws_off;             // float offset of the job's slabs in the workspace
-};
-constexpr int NJOBS = 39;
-struct GJobs {
-    GJob j[NJOBS];
-};
-
 template <int TA, int TB>
 struct Frags {
     f32x4 a[TA][4], b[TB][4];
@@ -419,21 +406,6 @@ __global__ __launch_bounds__(256, 1) void gblock_wgrad_bf16_kernel(const bf16_t*
     for (int u = 0; u < TB; ++u) slab[TA * TB * 1024 + u * 64 + lane] = bs[u];
 }
 
-// job numbering (see build_jobs): 0-3 W1, 4-9 D2_k, 10-11 W2, 12 W3, 13 W4, 14-19 D1_k,
-// 20-31 K2_k[b], 32-37 K1_k, 38 K0
-struct JobShape {
-    int ta, tb;
-};
-__host__ __device__ inline JobShape job_shape(int j) {
-    if (j < 10) return {2, 4};
-    if (j < 12) return {4, 2};
-    if (j < 13) return {2, 1};
-    if (j < 20) return {1, 1};
-    if (j < 32) return {1, 2};
-    if (j < 38) return {4, 1};
-    return {1, 4};
-}
-
 // sum over the job's slabs of accumulator element (tile, ci, co)
 // Partial sums are taken by 8 cooperating threads per element (thread `sub` adds slabs sub, sub+8,
 // ...); gblock_unpack_kernel then adds the 8 partials in a fixed order.
@@ -548,55 +520,6 @@ __global__ __launch_bounds__(256) void gblock_unpack_kernel(mgx_gblock_grads g, 
     if (live && sub == 0) *dst += total;
 }
 
-// launches per accumulator shape: first job, number of jobs
-struct ShapeRun {
-    int ta, tb, job0, njobs;
-    int wg_per_cu;      // resident workgroups per CU at the kernel's register use
-};
-const ShapeRun kRuns[7] = {{2, 4, 0, 10, 1}, {4, 2, 10, 2, 1}, {2, 1, 12, 1, 3}, {1, 1, 13, 7, 5}, {1, 2, 20, 12, 3},
-                           {4, 1, 32, 6, 2}, {1, 4, 38, 1, 2}};
-
-// workgroups per job: the jobs of a launch together fill the chip's resident slots exactly once (a
-// partly filled second round would idle most CUs), at most 256 per job (1024 slabs)
-int grid_x(long ntiles, const ShapeRun& run) {
-    long x = (ntiles + 3) / 4;
-    long cap = (256L * run.wg_per_cu) / run.njobs;
-    if (cap > 256) cap = 256;
-    cap &= ~7L;         // a multiple of 8 workgroups per job: lets the kernel keep a slab's jobs on one XCD
-    if (x > cap) x = cap;
-    return (int)(x < 1 ? 1 : x);
-}
-
-// Fill the job table for `ntiles` position tiles; returns the workspace size in floats.
-long build_jobs(GJobs& J, long ntiles) {
-    auto set = [&](int j, int rowA, int rowB, int nsub, int sA, int sB, int bias) {
-        J.j[j] = GJob{rowA, rowB, nsub, sA, sB, bias, 0, 0, 0};
-    };
-    for (int ab = 0; ab < 2; ++ab)
-        for (int bb = 0; bb < 2; ++bb) set(ab * 2 + bb, GB_S + 64 * ab, GB_T1 + 128 * bb, 4, 128, 256, ab == 0);
-    for (int k = 0; k < 6; ++k) set(4 + k, GB_BR + k * GB_BR_ROWS + GB_O3, GB_S, 4, 64, 128, k == 0);
-    for (int ab = 0; ab < 2; ++ab) set(10 + ab, GB_T1 + 128 * ab, GB_T2, 4, 256, 64, ab == 0);
-    set(12, GB_T2, GB_T3, 4, 64, 8, 1);
-    set(13, GB_T3, GB_X, 4, 8, 2, 1);
-    for (int k = 0; k < 6; ++k) {
-        const int br = GB_BR + k * GB_BR_ROWS;
-        set(14 + k, br + GB_O1, br + GB_O2, 2, 16, 32, 1);
-        for (int b = 0; b < 2; ++b) set(20 + k * 2 + b, br + GB_O2, br + GB_O3 + 64 * b, 2, 32, 128, 1);
-        set(32 + k, GB_F, br + GB_O1, 1, 0, 0, 1);
-    }
-    set(38, GB_X, GB_F, 1, 0, 0, 1);
-    long off = 0;
-    for (const ShapeRun& run : kRuns) {
-        const int nsplit = grid_x(ntiles, run) * 4;
-        for (int j = run.job0; j < run.job0 + run.njobs; ++j) {
-            J.j[j].nsplit = nsplit;
-            J.j[j].ws_off = off;
-            off += (long)nsplit * (run.ta * run.tb * 1024L + run.tb * 64L);
-        }
-    }
-    return off;
-}
-
 template <int TA, int TB>
 void launch_wgrad(const ShapeRun& run, const float* act, const float* delta, const GJobs& J, float* ws, long ntiles,
                   hipStream_t st) {
@@ -625,7 +548,9 @@ extern "C" int64_t mgx_gblock_packt_floats(void) { return PACKT_FLOATS + FRAG_SL
 extern "C" int64_t mgx_gblock_wgrad_workspace_n(int64_t npos) {
     if (npos <= 0) return 0;
     GJobs J;
-    return build_jobs(J, ((npos + 127) / 128) * 4) * (int64_t)sizeof(float);
+    const long ntiles = ((npos + 127) / 128) * 4;
+    const long full = build_jobs(J, ntiles), lean = build_jobs(J, ntiles, true);     // either entry point may follow
+    return (full > lean ? full : lean) * (int64_t)sizeof(float);
 }
 
 extern "C" int64_t mgx_gblock_wgrad_workspace(int64_t nimg, int hl, int wl) {
@@ -692,6 +617,34 @@ extern "C" int mgx_gblock_wgrad_bf16(const void* act, const void* delta, const m
     launch_wgrad_b<2, 1>(kRuns[2], a, d, J, ws, ntiles, st);
     launch_wgrad_b<1, 1>(kRuns[3], a, d, J, ws, ntiles, st);
     launch_wgrad_b<1, 2>(kRuns[4], a, d, J, ws, ntiles, st);
+    launch_wgrad_b<4, 1>(kRuns[5], a, d, J, ws, ntiles, st);
+    launch_wgrad_b<1, 4>(kRuns[6], a, d, J, ws, ntiles, st);
+    hipLaunchKernelGGL(gblock_unpack_kernel, dim3((N_PARAMS * 8 + 255) / 256), dim3(256), 0, st, g, J, ws);
+    return mgx_launch_status();
+}
+
+// gblock_lean.hip
+int mgx_gblock_lean_launch(const mgx_gblock_weights& w, const void* act, const void* delta, const GJobs& J, float* ws,
+                           long ntiles, hipStream_t st);
+
+extern "C" int mgx_gblock_wgrad_bf16_lean(const mgx_gblock_weights* wp, const void* act, const void* delta,
+                                          const mgx_gblock_grads* gp, void* workspace, int64_t workspace_bytes,
+                                          int64_t npos, void* stream) {
+    if (!wp || !act || !delta || !gp || !workspace || npos <= 0) return MGX_ERR_ARG;
+    const mgx_gblock_grads g = *gp;
+    const mgx_gblock_weights w = *wp;
+    if (!all_set(&g, sizeof(g)) || !all_set(&w, sizeof(w))) return MGX_ERR_ARG;
+    const long ntiles = ((npos + 127) / 128) * 4;
+    GJobs J;
+    const long need = build_jobs(J, ntiles, true);
+    if (workspace_bytes < need * (int64_t)sizeof(float)) return MGX_ERR_WORKSPACE;
+    hipStream_t st = (hipStream_t)stream;
+    float* ws = (float*)workspace;
+    const bf16_t* a = (const bf16_t*)act;
+    const bf16_t* d = (const bf16_t*)delta;
+    if (mgx_gblock_lean_launch(w, act, delta, J, ws, ntiles, st) != MGX_OK) return MGX_ERR_LAUNCH;
+    launch_wgrad_b<2, 1>(kRuns[2], a, d, J, ws, ntiles, st);
+    launch_wgrad_b<1, 1>(kRuns[3], a, d, J, ws, ntiles, st);
     launch_wgrad_b<4, 1>(kRuns[5], a, d, J, ws, ntiles, st);
     launch_wgrad_b<1, 4>(kRuns[6], a, d, J, ws, ntiles, st);
     hipLaunchKernelGGL(gblock_unpack_kernel, dim3((N_PARAMS * 8 + 255) / 256), dim3(256), 0, st, g, J, ws);

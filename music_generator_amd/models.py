@@ -378,7 +378,7 @@ def _register_fused_block(block_end, upsampling, for_sum_layer):
         y = K.empty((n, 2 * hl, 2 * wl, 2))
         act = K.empty((side,), dtype=torch.bfloat16 if bf else torch.float32)
         if bf:
-            ops.gblock_fwd_bf16(w, packb(x), x, y, n, hl, wl, act=act)
+            ops.gblock_fwd_bf16(w, packb(x), x, y, n, hl, wl, act=act, lean=K.GBLOCK_LEAN_TAPE)
         else:
             ops.gblock_fwd(w, pack(), x, y, n, hl, wl, act=act)
         return y, (act, None, (n, hl, wl), bf, None)
@@ -391,10 +391,16 @@ def _register_fused_block(block_end, upsampling, for_sum_layer):
             state[key] = torch.empty((ops.gblock_packt_bf16_bytes(),), dtype=torch.uint8, device=dy.device) if bf \
                 else K.empty((ops.gblock_packt_floats(),))
         packt = state[key]
-        fwd = (lambda **kw: ops.gblock_fwd_bf16(w, packb(dy), x, None, n, hl, wl, **kw)) if bf else \
+        # bf16: the tape is written without the four tensors the weight gradients recompute from their neighbours
+        # (K.GBLOCK_LEAN_TAPE); those kernels ignore the rows either way, so a tape written in full is accepted too
+        lean = bf and K.GBLOCK_LEAN_TAPE
+        fwd = (lambda **kw: ops.gblock_fwd_bf16(w, packb(dy), x, None, n, hl, wl, lean=lean, **kw)) if bf else \
               (lambda **kw: ops.gblock_fwd(w, pack(), x, None, n, hl, wl, **kw))
-        dgrad = ops.gblock_dgrad_bf16 if bf else ops.gblock_dgrad
-        wgrad = ops.gblock_wgrad_bf16 if bf else ops.gblock_wgrad
+        if bf:
+            dgrad = lambda *a, **kw: ops.gblock_dgrad_bf16(*a, lean=lean, **kw)
+            wgrad = lambda a, d, g, cnt: ops.gblock_wgrad_bf16(a, d, g, cnt, weights=w if lean else None)
+        else:
+            dgrad, wgrad = ops.gblock_dgrad, ops.gblock_wgrad
         side_of = ops.gblock_side_elems_bf16 if bf else ops.gblock_side_floats
         grads = None
         if need_weight_grads:

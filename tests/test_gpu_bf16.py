@@ -565,6 +565,47 @@ def test_bf16_generator_backward_matches_oracle(stage, twin, budget):
         assert err <= tol, "%s: rel-L2 %.3e" % (k, err)
 
 
+@pytest.mark.parametrize("budget", [None, 64 << 20])
+def test_bf16_generator_lean_tape_matches_full_tape(budget):
+    """The grow blocks' backward with the four widest tensors recomputed by the weight-gradient kernels
+    (backend.GBLOCK_LEAN_TAPE, the default) against the backward that reads every operand from a full tape, same
+    weights, latent points and output gradient, stage-2 fade-in generator (two grow blocks).  The recomputed
+    operands are the same bf16 roundings of the same float32 sums up to the order in which an MFMA adds its 16
+    products, so the two differ by a few flipped bf16 roundings: every gradient tensor relative L2 <= 2e-3, the
+    audio bit-identical (the forward arithmetic does not change)."""
+    from music_generator_amd.graph import FusedGroup
+    stage = 2
+    d, g, comp, W = _build(stage + 1)
+    model = g[stage][1]
+    for layer in model.layers:
+        if isinstance(layer, M.WeightedSum):
+            M.backend.set_value(layer.alpha, 0.37)
+    batch = 2
+    _, z4 = R.synthetic_inputs(stage, batch, seed=0)
+    h, w = 4 << stage, 750 << stage
+    dy = torch.from_numpy(np.random.default_rng(9).standard_normal((batch, h, w, 2)).astype(np.float32)).cuda()
+    out = {}
+    M.backend.set_precision("bfloat16")
+    FusedGroup.side_budget_bytes = budget
+    try:
+        for lean in (False, True):
+            M.backend.GBLOCK_LEAN_TAPE = lean
+            y, tape = model.forward(torch.from_numpy(z4[0]).cuda(), save=True)
+            model.bind_grads().zero_()
+            model.backward(tape, dy, need_input_grad=False)
+            torch.cuda.synchronize()
+            out[lean] = (y.clone(), {v.name: v.grad.clone() for v in model.trainable_variables})
+    finally:
+        M.backend.GBLOCK_LEAN_TAPE = True
+        M.backend.set_precision("float32")
+        FusedGroup.side_budget_bytes = None
+    assert torch.equal(out[False][0], out[True][0])
+    errs = {k: rel_l2(out[True][1][k].cpu().numpy(), out[False][1][k].cpu().numpy()) for k in out[False][1]}
+    print("lean against full tape, worst:", sorted(errs.items(), key=lambda kv: -kv[1])[:5])
+    for k, err in errs.items():
+        assert err <= 2e-3, "%s: rel-L2 %.3e" % (k, err)
+
+
 def _fresh_gan(stage, micro_batch, budget_gib=None, seed=11):
     from music_generator_amd.graph import FusedGroup
     M.clear_session()
