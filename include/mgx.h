@@ -459,14 +459,16 @@ int mgx_gblock_dgrad_bf16(const mgx_gblock_weights* w, void* packt, const float*
                           int64_t nimg, int hl, int wl, int64_t pos0, int64_t npos, void* stream);
 int mgx_gblock_wgrad_bf16(const void* act, const void* delta, const mgx_gblock_grads* g, void* workspace,
                           int64_t workspace_bytes, int64_t npos, void* stream);
-/* The same gradients without four of the tape's tensors: the output of the six Conv2DTranspose(64) and of Dense(256)
- * (models.py:377-378, 386) and the gradients that arrive at them make up 5120 of the 8138 rows of a 32-position tile
- * of the side buffers, and each is one linear layer away from rows the tape keeps.  mgx_gblock_wgrad_bf16_lean
- * recomputes them tile by tile from those rows and the block's weights `w` (the values the forward ran with) and
- * never reads their rows of `act` / `delta`; it accepts buffers written by either pair of entry points.
- * mgx_gblock_fwd_bf16_lean / mgx_gblock_dgrad_bf16_lean are mgx_gblock_fwd_bf16 / _dgrad_bf16 that leave those rows
- * of `act` (required here) / `delta` unwritten: the buffers keep their size and row map, the backward moves 37 % of
- * the bytes.  Same workspace size (mgx_gblock_wgrad_workspace_n covers both). */
+/* The same three steps with a LEAN tape: the output of the six Conv2DTranspose(64) and of Dense(256)
+ * (models.py:377-378, 386) and the gradients that arrive at them make up 5120 of the 8138 rows that a 32-position
+ * tile of the two side buffers holds, and each is one linear layer away from rows the tape keeps.  The _lean
+ * entry points use side buffers without those rows (mgx_gblock_side_elems_bf16_lean(npos) bf16 elements each, 38 % of
+ * the full size; their own row map, so the three must be used together): the forward and the data gradient do not
+ * write them, and mgx_gblock_wgrad_bf16_lean recomputes them tile by tile from the neighbouring rows and the block's
+ * weights `w` (the values the forward ran with).  mgx_gblock_fwd_bf16_lean requires `act`.  Same scratch buffers and
+ * workspace size (mgx_gblock_wgrad_workspace_n covers both forms); results differ from the full-tape entry points by
+ * the order in which an MFMA adds its products (a few flipped bf16 roundings). */
+int64_t mgx_gblock_side_elems_bf16_lean(int64_t npos);
 int mgx_gblock_fwd_bf16_lean(const mgx_gblock_weights* w, void* packb, const float* x, float* y, void* act, int64_t nimg,
                              int hl, int wl, int64_t pos0, int64_t npos, void* stream);
 int mgx_gblock_dgrad_bf16_lean(const mgx_gblock_weights* w, void* packt, const float* dy, void* delta, float* dx,

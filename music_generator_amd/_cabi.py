@@ -146,6 +146,7 @@ PROTOTYPES = {
     "mgx_gblock_fwd_bf16": (_I, [C.POINTER(GBlockWeights), _P, _P, _P, _P, _I64, _I, _I, _I64, _I64, _P]),
     "mgx_gblock_dgrad_bf16": (_I, [C.POINTER(GBlockWeights), _P, _P, _P, _P, _I64, _I, _I, _I64, _I64, _P]),
     "mgx_gblock_wgrad_bf16": (_I, [_P, _P, C.POINTER(GBlockWeights), _P, _I64, _I64, _P]),
+    "mgx_gblock_side_elems_bf16_lean": (_I64, [_I64]),
     "mgx_gblock_fwd_bf16_lean": (_I, [C.POINTER(GBlockWeights), _P, _P, _P, _P, _I64, _I, _I, _I64, _I64, _P]),
     "mgx_gblock_dgrad_bf16_lean": (_I, [C.POINTER(GBlockWeights), _P, _P, _P, _P, _I64, _I, _I, _I64, _I64, _P]),
     "mgx_gblock_wgrad_bf16_lean": (_I, [C.POINTER(GBlockWeights), _P, _P, C.POINTER(GBlockWeights), _P, _I64, _I64, _P]),

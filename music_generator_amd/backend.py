@@ -8,6 +8,8 @@ import re
 from typing import Dict, Optional, Tuple
 
 import numpy as np
+import os
+
 import torch
 
 _name_counts: Dict[str, int] = {}
@@ -135,7 +137,7 @@ BF16_SAVE_DERIVATIVE = False
 # bf16 generator grow blocks: leave the outputs of the Conv2DTranspose(64) / Dense(256) layers and the gradients
 # arriving at them off the tape (5120 of its 8138 rows per 32 positions); the weight-gradient kernels recompute
 # them from the neighbouring rows.  False: every tensor on the tape, every weight gradient read from it.
-GBLOCK_LEAN_TAPE = True
+GBLOCK_LEAN_TAPE = os.environ.get("MGX_GBLOCK_LEAN", "1") != "0"
 
 
 def set_precision(name: str):

@@ -128,7 +128,9 @@ __device__ __forceinline__ void init_bias(f32x16& acc, const float* __restrict__
 // only ever touched by MFMAs until the sub-row's tail, so that 128 vector registers stay free for the operand
 // reads to run ahead.  The compiler does not see this instruction: mfma_result_wait() before the tile is read.
 __device__ __forceinline__ void mfma_bf16_pinned(f32x16& c, u32x4 a, u32x4 b) {
-    asm volatile("v_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
+    // s_nop 1: the two wait states between a vector-ALU write of an operand (the conversion that produced `b`) and the
+    // MFMA that reads it; the compiler pads them for MFMAs it emits itself, never inside an asm statement
+    asm volatile("s_nop 1\n\tv_mfma_f32_32x32x16_bf16 %0, %1, %2, %0" : "+a"(c) : "v"(a), "v"(b));
 }
 
 // B operand of the next layer: k-step s = registers 8s .. 8s+7 as bf16
@@ -229,11 +231,13 @@ __device__ __forceinline__ void stage(const unsigned char* __restrict__ packb, i
 
 // NW waves per workgroup share the staged weight fragments: 4 (one per SIMD), or 8 for the forward that keeps no tape
 // (two per SIMD: the conversions of one wave run beside the MFMAs of the other)
-template <bool SAVE, int NW>
+template <bool SAVE, int NW, class RM>
 __global__ __launch_bounds__(64 * NW, 1) void gblock_fwd_bf16_kernel(const unsigned char* __restrict__ packb,
                                                                  const float* __restrict__ x, float* __restrict__ y,
                                                                  bf16_t* __restrict__ act, long pos0, long npix, int hl,
-                                                                 int wl, long ntiles, int lean) {
+                                                                 int wl, long ntiles) {
+    GB_USE_ROWS(RM);
+    constexpr bool lean = RM::lean;      // the weight gradients recompute what a lean tape leaves out (gblock_lean.hip)
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -328,7 +332,6 @@ __global__ __launch_bounds__(64 * NW, 1) void gblock_fwd_bf16_kernel(const unsig
                         for (int ks = 0; ks < 2; ++ks)
                             o3 = mfma_bf16(frag(wb, FB_K2 + (b * 2 + ot) * 2 + ks, lane), o2b.k[ks], o3);
                         o3b[ot] = to_b(o3);
-                        // lean tape: the weight gradients recompute this tensor from o2 (gblock_lean.hip)
                         if (SAVE && !lean) save_b<2>(abr, GB_O3 + (A * 2 + b) * 64 + ot * 32, o3b[ot], r, h, tl);
                     }
                     // the four output tiles innermost: an MFMA that continues the accumulator of the one before it
@@ -501,11 +504,13 @@ __device__ __forceinline__ void zero_tile(f32x16& t) {
     for (int i = 0; i < 16; ++i) t[i] = 0.f;
 }
 
+template <class RM>
 __global__ __launch_bounds__(256, 1) void gblock_dgrad_bf16_kernel(const unsigned char* __restrict__ packt,
                                                                    const float* __restrict__ dy,
                                                                    bf16_t* __restrict__ delta, float* __restrict__ dx,
-                                                                   long pos0, long npix, int hl, int wl, long ntiles,
-                                                                   int lean) {
+                                                                   long pos0, long npix, int hl, int wl, long ntiles) {
+    GB_USE_ROWS(RM);
+    constexpr bool lean = RM::lean;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
@@ -674,6 +679,9 @@ extern "C" int64_t mgx_gblock_packt_bf16_bytes(void) { return (int64_t)NFT * 102
 extern "C" int64_t mgx_gblock_side_elems_bf16(int64_t npos) {
     return npos <= 0 ? 0 : ((npos + 127) / 128) * 4 * (GB_ROWS * 32L);
 }
+extern "C" int64_t mgx_gblock_side_elems_bf16_lean(int64_t npos) {
+    return npos <= 0 ? 0 : ((npos + 127) / 128) * 4 * (GbRowsLean::ROWS * 32L);
+}
 
 namespace {
 bool weights_set(const mgx_gblock_weights& w) {
@@ -708,26 +716,32 @@ static int gblock_fwd_bf16_any(const mgx_gblock_weights* wp, void* packb, const 
     if (pos0 == 0)      // the packed fragments of a call sequence over ranges are filled by its first call
         hipLaunchKernelGGL(gblock_pack_bf16_kernel, dim3((NFB * 512 + 255) / 256), dim3(256), 0, st, w, (unsigned char*)packb);
     const unsigned grid = (unsigned)(ntiles < 256 ? ntiles : 256);
-    if (act) {
-        if (hipFuncSetAttribute((const void*)gblock_fwd_bf16_kernel<true, 4>, hipFuncAttributeMaxDynamicSharedMemorySize,
-                                LDS_BYTES) != hipSuccess)
+    if (act && lean) {
+        if (hipFuncSetAttribute((const void*)gblock_fwd_bf16_kernel<true, 4, GbRowsLean>,
+                                hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess)
             return MGX_ERR_LAUNCH;
-        hipLaunchKernelGGL((gblock_fwd_bf16_kernel<true, 4>), dim3(grid), dim3(256), LDS_BYTES, st,
-                           (const unsigned char*)packb, x, y, (bf16_t*)act, (long)pos0, end, hl, wl, ntiles, lean);
+        hipLaunchKernelGGL((gblock_fwd_bf16_kernel<true, 4, GbRowsLean>), dim3(grid), dim3(256), LDS_BYTES, st,
+                           (const unsigned char*)packb, x, y, (bf16_t*)act, (long)pos0, end, hl, wl, ntiles);
+    } else if (act) {
+        if (hipFuncSetAttribute((const void*)gblock_fwd_bf16_kernel<true, 4, GbRowsFull>,
+                                hipFuncAttributeMaxDynamicSharedMemorySize, LDS_BYTES) != hipSuccess)
+            return MGX_ERR_LAUNCH;
+        hipLaunchKernelGGL((gblock_fwd_bf16_kernel<true, 4, GbRowsFull>), dim3(grid), dim3(256), LDS_BYTES, st,
+                           (const unsigned char*)packb, x, y, (bf16_t*)act, (long)pos0, end, hl, wl, ntiles);
     } else if (fwd_waves() == 8) {
         const long nt8 = (end - pos0 + 255) / 256;
         const unsigned grid8 = (unsigned)(nt8 < 256 ? nt8 : 256);
-        if (hipFuncSetAttribute((const void*)gblock_fwd_bf16_kernel<false, 8>, hipFuncAttributeMaxDynamicSharedMemorySize,
+        if (hipFuncSetAttribute((const void*)gblock_fwd_bf16_kernel<false, 8, GbRowsFull>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 LDS_BYTES) != hipSuccess)
             return MGX_ERR_LAUNCH;
-        hipLaunchKernelGGL((gblock_fwd_bf16_kernel<false, 8>), dim3(grid8), dim3(512), LDS_BYTES, st,
-                           (const unsigned char*)packb, x, y, (bf16_t*)nullptr, (long)pos0, end, hl, wl, nt8, 0);
+        hipLaunchKernelGGL((gblock_fwd_bf16_kernel<false, 8, GbRowsFull>), dim3(grid8), dim3(512), LDS_BYTES, st,
+                           (const unsigned char*)packb, x, y, (bf16_t*)nullptr, (long)pos0, end, hl, wl, nt8);
     } else {
-        if (hipFuncSetAttribute((const void*)gblock_fwd_bf16_kernel<false, 4>, hipFuncAttributeMaxDynamicSharedMemorySize,
+        if (hipFuncSetAttribute((const void*)gblock_fwd_bf16_kernel<false, 4, GbRowsFull>, hipFuncAttributeMaxDynamicSharedMemorySize,
                                 LDS_BYTES) != hipSuccess)
             return MGX_ERR_LAUNCH;
-        hipLaunchKernelGGL((gblock_fwd_bf16_kernel<false, 4>), dim3(grid), dim3(256), LDS_BYTES, st,
-                           (const unsigned char*)packb, x, y, (bf16_t*)nullptr, (long)pos0, end, hl, wl, ntiles, 0);
+        hipLaunchKernelGGL((gblock_fwd_bf16_kernel<false, 4, GbRowsFull>), dim3(grid), dim3(256), LDS_BYTES, st,
+                           (const unsigned char*)packb, x, y, (bf16_t*)nullptr, (long)pos0, end, hl, wl, ntiles);
     }
     return mgx_launch_status();
 }
@@ -755,12 +769,16 @@ static int gblock_dgrad_bf16_any(const mgx_gblock_weights* wp, void* packt, cons
     const long ntiles = (end - pos0 + 127) / 128;
     if (pos0 == 0)
         hipLaunchKernelGGL(gblock_packT_bf16_kernel, dim3((NFT * 512 + 255) / 256), dim3(256), 0, st, w, (unsigned char*)packt);
-    if (hipFuncSetAttribute((const void*)gblock_dgrad_bf16_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, TLDS_BYTES) !=
-        hipSuccess)
-        return MGX_ERR_LAUNCH;
     const unsigned grid = (unsigned)(ntiles < 256 ? ntiles : 256);
-    hipLaunchKernelGGL(gblock_dgrad_bf16_kernel, dim3(grid), dim3(256), TLDS_BYTES, st, (const unsigned char*)packt, dy,
-                       (bf16_t*)delta, dx, (long)pos0, end, hl, wl, ntiles, lean);
+    auto launch = [&](auto kernel) {
+        if (hipFuncSetAttribute((const void*)kernel, hipFuncAttributeMaxDynamicSharedMemorySize, TLDS_BYTES) != hipSuccess)
+            return false;
+        hipLaunchKernelGGL(kernel, dim3(grid), dim3(256), TLDS_BYTES, st, (const unsigned char*)packt, dy, (bf16_t*)delta, dx,
+                           (long)pos0, end, hl, wl, ntiles);
+        return true;
+    };
+    if (!(lean ? launch(gblock_dgrad_bf16_kernel<GbRowsLean>) : launch(gblock_dgrad_bf16_kernel<GbRowsFull>)))
+        return MGX_ERR_LAUNCH;
     return mgx_launch_status();
 }
 

@@ -235,7 +235,7 @@ template <int TA, int TB>
 __device__ __forceinline__ void load_frags(Frags<TA, TB>& f, const float* __restrict__ act,
                                            const float* __restrict__ delta, const GJob& jb, long pt, int sub, int i,
                                            int h) {
-    const float* pa = act + (pt * GB_ROWS + jb.rowA + sub * jb.strideA + i) * 32L + 16 * h;
+    const float* pa = act + (pt * GB_ROWS + jb.rowA + sub * jb.strideA + i) * 32L + 16 * h;      // float32: always the full map
     const float* pb = delta + (pt * GB_ROWS + jb.rowB + sub * jb.strideB + i) * 32L + 16 * h;
 #pragma unroll
     for (int t = 0; t < TA; ++t)
@@ -328,10 +328,10 @@ struct FragsB {
 
 template <int TA, int TB>
 __device__ __forceinline__ void load_frags_b(FragsB<TA, TB>& f, const bf16_t* __restrict__ act,
-                                             const bf16_t* __restrict__ delta, const GJob& jb, long pt, int sub, int i,
-                                             int h) {
-    const bf16_t* pa = act + (pt * GB_ROWS + jb.rowA + sub * jb.strideA + i) * 32L + 8 * h;
-    const bf16_t* pb = delta + (pt * GB_ROWS + jb.rowB + sub * jb.strideB + i) * 32L + 8 * h;
+                                             const bf16_t* __restrict__ delta, const GJob& jb, long rows, long pt, int sub,
+                                             int i, int h) {
+    const bf16_t* pa = act + (pt * rows + jb.rowA + sub * jb.strideA + i) * 32L + 8 * h;
+    const bf16_t* pb = delta + (pt * rows + jb.rowB + sub * jb.strideB + i) * 32L + 8 * h;
 #pragma unroll
     for (int t = 0; t < TA; ++t)
 #pragma unroll
@@ -369,13 +369,14 @@ __global__ __launch_bounds__(256, 1) void gblock_wgrad_bf16_kernel(const bf16_t*
     long pt = split;
     int sub = 0;
     FragsB<TA, TB> cur, nxt;
-    if (pt < ntiles) load_frags_b<TA, TB>(cur, act, delta, jb, pt, 0, i, h);
+    const long rows = jobs.rows;
+    if (pt < ntiles) load_frags_b<TA, TB>(cur, act, delta, jb, rows, pt, 0, i, h);
     while (pt < ntiles) {
         long ptn = pt;
         int subn = sub + 1;
         if (subn == jb.nsub) { subn = 0; ptn = pt + nw; }
         const bool more = ptn < ntiles;
-        if (more) load_frags_b<TA, TB>(nxt, act, delta, jb, ptn, subn, i, h);
+        if (more) load_frags_b<TA, TB>(nxt, act, delta, jb, rows, ptn, subn, i, h);
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks)
 #pragma unroll

@@ -18,6 +18,8 @@ struct GJob {
 constexpr int NJOBS = 39;
 struct GJobs {
     GJob j[NJOBS];
+    int rows;                // rows per position tile of the side buffers the jobs read (GbRowsFull / GbRowsLean)
+    int pad;
 };
 
 // job numbering (see build_jobs): 0-3 W1, 4-9 D2_k, 10-11 W2, 12 W3, 13 W4, 14-19 D1_k,
@@ -64,25 +66,34 @@ static inline int lean_grid_x(long ntiles, int njobs) {
 }
 static inline bool lean_job(int j) { return j < 12 || (j >= 20 && j < 32); }
 
-// Fill the job table for `ntiles` position tiles; returns the workspace size in floats.  `lean`: the jobs the
-// recomputing kernels serve get those kernels' split counts.
-static inline long build_jobs(GJobs& J, long ntiles, bool lean = false) {
+// Fill the job table for `ntiles` position tiles; returns the workspace size in floats.  `lean`: side buffers with
+// the lean row map; the jobs the recomputing kernels serve (their operands are not on such a tape) get those
+// kernels' split counts and no rows.
+template <class RM>
+static inline void set_job_rows(GJobs& J) {
     auto set = [&](int j, int rowA, int rowB, int nsub, int sA, int sB, int bias) {
         J.j[j] = GJob{rowA, rowB, nsub, sA, sB, bias, 0, 0, 0};
     };
     for (int ab = 0; ab < 2; ++ab)
-        for (int bb = 0; bb < 2; ++bb) set(ab * 2 + bb, GB_S + 64 * ab, GB_T1 + 128 * bb, 4, 128, 256, ab == 0);
-    for (int k = 0; k < 6; ++k) set(4 + k, GB_BR + k * GB_BR_ROWS + GB_O3, GB_S, 4, 64, 128, k == 0);
-    for (int ab = 0; ab < 2; ++ab) set(10 + ab, GB_T1 + 128 * ab, GB_T2, 4, 256, 64, ab == 0);
-    set(12, GB_T2, GB_T3, 4, 64, 8, 1);
-    set(13, GB_T3, GB_X, 4, 8, 2, 1);
+        for (int bb = 0; bb < 2; ++bb) set(ab * 2 + bb, RM::S + 64 * ab, RM::T1 + 128 * bb, 4, 128, 256, ab == 0);
+    for (int k = 0; k < 6; ++k) set(4 + k, RM::BR + k * RM::BR_ROWS + RM::O3, RM::S, 4, 64, 128, k == 0);
+    for (int ab = 0; ab < 2; ++ab) set(10 + ab, RM::T1 + 128 * ab, RM::T2, 4, 256, 64, ab == 0);
+    set(12, RM::T2, RM::T3, 4, 64, 8, 1);
+    set(13, RM::T3, RM::X, 4, 8, 2, 1);
     for (int k = 0; k < 6; ++k) {
-        const int br = GB_BR + k * GB_BR_ROWS;
-        set(14 + k, br + GB_O1, br + GB_O2, 2, 16, 32, 1);
-        for (int b = 0; b < 2; ++b) set(20 + k * 2 + b, br + GB_O2, br + GB_O3 + 64 * b, 2, 32, 128, 1);
-        set(32 + k, GB_F, br + GB_O1, 1, 0, 0, 1);
+        const int br = RM::BR + k * RM::BR_ROWS;
+        set(14 + k, br + RM::O1, br + RM::O2, 2, 16, 32, 1);
+        for (int b = 0; b < 2; ++b) set(20 + k * 2 + b, br + RM::O2, br + RM::O3 + 64 * b, 2, 32, 128, 1);
+        set(32 + k, RM::F, br + RM::O1, 1, 0, 0, 1);
     }
-    set(38, GB_X, GB_F, 1, 0, 0, 1);
+    set(38, RM::X, RM::F, 1, 0, 0, 1);
+    J.rows = RM::ROWS;
+    J.pad = 0;
+}
+
+static inline long build_jobs(GJobs& J, long ntiles, bool lean = false) {
+    if (lean) set_job_rows<GbRowsLean>(J);
+    else set_job_rows<GbRowsFull>(J);
     long off = 0;
     for (const ShapeRun& run : kRuns) {
         for (int j = run.job0; j < run.job0 + run.njobs; ++j) {

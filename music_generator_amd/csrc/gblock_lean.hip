@@ -12,9 +12,14 @@
 // Recomputing product: D[pos][co] = sum_ci X[ci][pos] W[ci][co].  Lane (r, h) supplies A[row r = pos][k = 8h+j]
 // = X[ci0 + 8h + j][pos r], which ds_read_b64_tr_b16 delivers from rows staged as they lie in the side buffer
 // (32 positions = 64 bytes a row), and B[k][col r] = W[ci0 + 8h + j][co r] from a register fragment loaded once
-// per kernel.  The result tile holds, in lane (co, h), register 8s + j = position (j&3) + 8((j>>2) + 2s) + 4h: as
-// bf16 the registers 8s .. 8s+7 are one operand of weight-gradient k-step s with the 32 positions of the tile in
-// that (permuted) order, so the partner operand reads its row's positions in the same order: two 8-byte LDS reads.
+// per kernel.  The rows of A are handed out so that row m carries position 4 G(m >> 2) + (m & 3) with
+// G(g) = (g >> 1) + 4 (g & 1) (the transposing read takes its four 8-byte chunks from any positions): lane
+// (co, h) of the result then holds position 16 h + reg in register reg, and as bf16 the registers 8s .. 8s+7 are
+// one operand of weight-gradient k-step s = positions 16 h + 8 s .. + 7.  The partner operand contracts the same
+// positions in the same slots: 16 consecutive bytes of its staged row, one LDS read.
+// The rows reach LDS by LDS-DMA two steps ahead of their use (three buffers per wave).  The DMA is issued from
+// inline assembly: the compiler orders every LDS read behind all outstanding LDS-DMA it knows of (it cannot
+// tell the buffers apart), which would make each step wait for the rows of the steps after it.
 // Weight-gradient accumulators, slabs and bias sums have the layout of gblock_wgrad_bf16_kernel (gblock_bwd.hip),
 // whose gblock_unpack_kernel adds them into the gradient tensors.
 #include "bf16.h"
@@ -26,23 +31,31 @@
 namespace {
 
 // Staged rows: 64 bytes each, the four 16-byte chunks of row `row` XOR-swizzled with bits 2-3 of the row so that
-// the 8-byte reads of 32 consecutive rows (partner operands) spread over the banks; the transposing reads (4
+// the 16-byte reads of 16 consecutive rows (partner operands) cover all banks; the transposing reads (4
 // consecutive rows x 8 chunks of 8 bytes per half wave) are conflict-free with or without it.
 __device__ __forceinline__ int row_off(int row, int q8) {
     return row * 64 + ((((q8 >> 1) ^ (row >> 2)) & 3) << 4) + ((q8 & 1) << 3);
 }
 
+__device__ __forceinline__ unsigned lds_addr(const unsigned char* p) {
+    return (unsigned)(size_t)(__attribute__((address_space(3))) const void*)p;
+}
+
+// One LDS-DMA instruction: lane l fetches 16 bytes from its global address to LDS byte `dst` + 16 l (dst wave-uniform).
+__device__ __forceinline__ void dma16(const void* gptr, unsigned dst) {
+    asm volatile("s_mov_b32 m0, %0\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %1, off" ::"s"(dst), "v"(gptr) : "memory");
+}
+
 // NB blocks of 16 consecutive side-buffer rows starting at `src` -> staged rows row0 .. by LDS-DMA: lane l of a
 // block fills 16 bytes at row0 * 64 + 16 l and fetches the chunk of the row that belongs there.
 template <int NB>
-__device__ __forceinline__ void stage_rows(const bf16_t* __restrict__ src, unsigned char* buf, int row0, int lane) {
+__device__ __forceinline__ void stage_rows(const bf16_t* __restrict__ src, unsigned buf, int row0, int lane) {
     const int rl = lane >> 2, c = lane & 3;
 #pragma unroll
     for (int i = 0; i < NB; ++i) {
         const int row = row0 + 16 * i + rl;
         const int cg = (c ^ (row >> 2)) & 3;
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(src + (16 * i + rl) * 32 + cg * 8),
-                                         (__attribute__((address_space(3))) void*)(buf + (row0 + 16 * i) * 64), 16, 0, 0);
+        dma16(src + (16 * i + rl) * 32 + cg * 8, buf + (row0 + 16 * i) * 64);
     }
 }
 
@@ -50,17 +63,15 @@ __device__ __forceinline__ void stage_rows(const bf16_t* __restrict__ src, unsig
 __device__ __forceinline__ u32x4 tr_frag(const unsigned char* buf, int row0, int lane) {
     const int g16 = lane >> 4, q = (lane >> 2) & 3, p = lane & 3;
     const int row = row0 + 8 * (g16 >> 1) + q;
-    const int q8 = 4 * (g16 & 1) + p;
+    const int q8 = 2 * (g16 & 1) + (p >> 1) + 4 * (p & 1);          // G(4 (g16 & 1) + p)
     const u32x2 lo = tr_read(buf + row_off(row, q8));
     const u32x2 hi = tr_read(buf + row_off(row + 4, q8));
     return (u32x4){lo[0], lo[1], hi[0], hi[1]};
 }
 
-// Operand of weight-gradient k-step ks from staged row `row`, positions in the order of a recomputed tile
+// Operand of weight-gradient k-step ks from staged row `row`: positions 16 h + 8 ks .. + 7
 __device__ __forceinline__ u32x4 perm_frag(const unsigned char* buf, int row, int ks, int h) {
-    const u32x2 a = *(const u32x2*)(buf + row_off(row, 4 * ks + h));
-    const u32x2 b = *(const u32x2*)(buf + row_off(row, 4 * ks + 2 + h));
-    return (u32x4){a[0], a[1], b[0], b[1]};
+    return *(const u32x4*)(buf + row_off(row, 2 * (2 * h + ks)));
 }
 
 // registers 8s .. 8s+7 of a recomputed tile as bf16
@@ -71,11 +82,15 @@ __device__ __forceinline__ u32x4 to_op(const f32x16& a, int s) {
     return t;
 }
 
-__device__ __forceinline__ float sum8(u32x4 v) {
-    float s = 0.f;
+// acc + the eight bf16 values of a fragment: v_dot2c_f32_bf16 against (1, 1) adds both halves of a dword at once
+__device__ __forceinline__ float add8(float acc, u32x4 v) {
+    const bf16x2 ones = {(__bf16)1.0f, (__bf16)1.0f};
 #pragma unroll
-    for (int q = 0; q < 4; ++q) s += bf_lo(v[q]) + bf_hi(v[q]);
-    return s;
+    for (int q = 0; q < 4; ++q) {
+        const unsigned e = v[q];      // by value: __builtin_bit_cast applied to the element expression itself reads element 0
+        acc = __builtin_amdgcn_fdot2_f32_bf16(__builtin_bit_cast(bf16x2, e), ones, acc, false);
+    }
+    return acc;
 }
 
 // eight consecutive float32 weights -> one bf16 fragment (round to nearest even, as the packed forward weights)
@@ -89,7 +104,24 @@ __device__ __forceinline__ void splat(f32x16& t, float v) {
     for (int i = 0; i < 16; ++i) t[i] = v;
 }
 
-__device__ __forceinline__ void dma_wait() { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); }
+// Wait until at most `batches` of the most recent DMA batches (N instructions each) are still in flight: vector
+// memory operations complete in order, so everything issued before them has then landed.
+template <int N>
+__device__ __forceinline__ void dma_wait(int batches) {
+    if (batches >= 2) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(2 * N) : "memory");
+    else if (batches == 1) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+}
+
+// position-tile walk of one wave: sub-position ab of tile pt, then ab + 1, ..., then tile pt + nw
+struct Walk {
+    long pt;
+    int ab;
+};
+__device__ __forceinline__ Walk succ(Walk w, long nw) {
+    if (++w.ab == 4) { w.ab = 0; w.pt += nw; }
+    return w;
+}
 
 // all jobs of one slab index on one XCD: they stage the same rows, which then come from HBM once per XCD
 __device__ __forceinline__ void xcd_map(int& xb, int& job) {
@@ -119,7 +151,7 @@ __device__ __forceinline__ void put_tile(float* slab, int tile, const f32x16& ac
 // rows 0-31 d1_k of sub-row a, rows 32-159 dsum of ab.
 // ------------------------------------------------------------------------------------------
 constexpr int BR_ROWS = 160, BR_BUF = BR_ROWS * 64;
-constexpr int BR_LDS = 4 * 2 * BR_BUF;
+constexpr int BR_LDS = 4 * 3 * BR_BUF;
 
 __global__ __launch_bounds__(256, 1) void gblock_lean_branch_kernel(mgx_gblock_weights w, const bf16_t* __restrict__ act,
                                                                     const bf16_t* __restrict__ delta, GJobs jobs,
@@ -130,9 +162,10 @@ __global__ __launch_bounds__(256, 1) void gblock_lean_branch_kernel(mgx_gblock_w
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int r = lane & 31, h = lane >> 5;
-    unsigned char* buf = lds + wv * (2 * BR_BUF);
+    unsigned char* buf = lds + wv * (3 * BR_BUF);
     const long split = (long)xb * 4 + wv, nw = (long)gridDim.x * 4;
-    const int br = GB_BR + k * GB_BR_ROWS;
+    using RM = GbRowsLean;
+    const int br = RM::BR + k * RM::BR_ROWS;
 
     // weight fragments: K2_k[b][co][ci] as [ci][co] of (b, output tile ot, k-step), D2_k[in][out] as [out][in]
     u32x4 k2f[2][2][2], d2f[2][8];
@@ -158,69 +191,87 @@ __global__ __launch_bounds__(256, 1) void gblock_lean_branch_kernel(mgx_gblock_w
         for (int u = 0; u < 2; ++u) splat(accK[t][u], 0.f);
     }
 
-    auto issue = [&](long t, int ab, int par) {
-        stage_rows<2>(act + (t * GB_ROWS + br + GB_O2 + (ab >> 1) * 32) * 32L, buf + par * BR_BUF, 0, lane);
-        stage_rows<8>(delta + (t * GB_ROWS + GB_S + ab * 128) * 32L, buf + par * BR_BUF, 32, lane);
+    const unsigned lbase = lds_addr(buf);
+    auto issue = [&](Walk wk, int slot) {
+        stage_rows<2>(act + (wk.pt * RM::ROWS + br + RM::O2 + (wk.ab >> 1) * 32) * 32L, lbase + slot * BR_BUF, 0, lane);
+        stage_rows<8>(delta + (wk.pt * RM::ROWS + RM::S + wk.ab * 128) * 32L, lbase + slot * BR_BUF, 32, lane);
     };
     auto step = [&](auto bc, const unsigned char* cb) {
         constexpr int B = decltype(bc)::value;
-        // c2 of this sub-position from d1 (32 inputs: 2 k-steps), starting from the bias as the forward does
-        const u32x4 ad[2] = {tr_frag(cb, 0, lane), tr_frag(cb, 16, lane)};
-        u32x4 c2op[2][2];
+        // every LDS read of the step first: the MFMAs below start as their operands arrive
+        u32x4 ad[2], as[8], bsum[2][4], ad1[2];
 #pragma unroll
-        for (int ot = 0; ot < 2; ++ot) {
-            f32x16 c;
-            splat(c, b2v[ot]);
-#pragma unroll
-            for (int s = 0; s < 2; ++s) c = mfma_bf16(ad[s], k2f[B][ot][s], c);
-            c2op[ot][0] = to_op(c, 0);
-            c2op[ot][1] = to_op(c, 1);
-        }
-        // dc2 from dsum (128 inputs: 8 k-steps)
-        u32x4 as[8];
+        for (int s = 0; s < 2; ++s) ad[s] = tr_frag(cb, 16 * s, lane);
 #pragma unroll
         for (int s = 0; s < 8; ++s) as[s] = tr_frag(cb, 32 + 16 * s, lane);
-        u32x4 dcop[2][2];
-#pragma unroll
-        for (int it = 0; it < 2; ++it) {
-            f32x16 c;
-            splat(c, 0.f);
-#pragma unroll
-            for (int s = 0; s < 8; ++s) c = mfma_bf16(as[s], d2f[it][s], c);
-            dcop[it][0] = to_op(c, 0);
-            dcop[it][1] = to_op(c, 1);
-            bs2[it] += sum8(dcop[it][0]) + sum8(dcop[it][1]);
-        }
 #pragma unroll
         for (int s = 0; s < 2; ++s) {
 #pragma unroll
-            for (int u = 0; u < 4; ++u) {
-                const u32x4 bsum = perm_frag(cb, 32 + 32 * u + r, s, h);
-                bsS[u] += sum8(bsum);
-#pragma unroll
-                for (int t = 0; t < 2; ++t) accD[t][u] = mfma_bf16(c2op[t][s], bsum, accD[t][u]);
-            }
-            const u32x4 ad1 = perm_frag(cb, r, s, h);
-#pragma unroll
-            for (int u = 0; u < 2; ++u) accK[B][u] = mfma_bf16(ad1, dcop[u][s], accK[B][u]);
+            for (int u = 0; u < 4; ++u) bsum[s][u] = perm_frag(cb, 32 + 32 * u + r, s, h);
+            ad1[s] = perm_frag(cb, r, s, h);
         }
+        __builtin_amdgcn_sched_barrier(0);
+        // c2 of this sub-position from d1 (32 inputs: 2 k-steps), starting from the bias as the forward does;
+        // dc2 from dsum (128 inputs: 8 k-steps).  The four tiles advance together: no MFMA waits for the one before.
+        f32x16 c2[2], dc[2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+            splat(c2[t], b2v[t]);
+            splat(dc[t], 0.f);
+        }
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int t = 0; t < 2; ++t) c2[t] = mfma_bf16(ad[s], k2f[B][t][s], c2[t]);
+#pragma unroll
+        for (int s = 0; s < 8; ++s)
+#pragma unroll
+            for (int t = 0; t < 2; ++t) dc[t] = mfma_bf16(as[s], d2f[t][s], dc[t]);
+        u32x4 c2op[2][2], dcop[2][2];
+#pragma unroll
+        for (int t = 0; t < 2; ++t)
+#pragma unroll
+            for (int s = 0; s < 2; ++s) c2op[t][s] = to_op(c2[t], s);
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int u = 0; u < 4; ++u) {
+                bsS[u] = add8(bsS[u], bsum[s][u]);
+#pragma unroll
+                for (int t = 0; t < 2; ++t) accD[t][u] = mfma_bf16(c2op[t][s], bsum[s][u], accD[t][u]);
+            }
+#pragma unroll
+        for (int t = 0; t < 2; ++t) {
+#pragma unroll
+            for (int s = 0; s < 2; ++s) dcop[t][s] = to_op(dc[t], s);
+            bs2[t] = add8(add8(bs2[t], dcop[t][0]), dcop[t][1]);
+        }
+#pragma unroll
+        for (int s = 0; s < 2; ++s)
+#pragma unroll
+            for (int u = 0; u < 2; ++u) accK[B][u] = mfma_bf16(ad1[s], dcop[u][s], accK[B][u]);
     };
 
-    long pt = split;
-    int a = 0, par = 0;
-    if (pt < ntiles) issue(pt, 0, 0);
-    while (pt < ntiles) {
-        dma_wait();
-        issue(pt, 2 * a + 1, par ^ 1);
-        step(std::integral_constant<int, 0>{}, buf + par * BR_BUF);
-        par ^= 1;
-        const long ptn = a ? pt + nw : pt;
-        dma_wait();
-        if (ptn < ntiles) issue(ptn, a ? 0 : 2, par ^ 1);
-        step(std::integral_constant<int, 1>{}, buf + par * BR_BUF);
-        par ^= 1;
-        pt = ptn;
-        a ^= 1;
+    // three staging buffers: the rows of step i + 2 are requested before step i is computed
+    Walk w0 = {split, 0};
+    Walk w1 = succ(w0, nw), w2 = succ(w1, nw);
+    if (w0.pt < ntiles) issue(w0, 0);
+    if (w1.pt < ntiles) issue(w1, 1);
+    int slot = 0;
+    auto advance = [&](auto bc) {
+        const int s2 = slot == 0 ? 2 : slot - 1;                     // (slot + 2) % 3: read two steps ago
+        if (w2.pt < ntiles) issue(w2, s2);
+        dma_wait<10>((w1.pt < ntiles) + (w2.pt < ntiles));
+        step(bc, buf + slot * BR_BUF);
+        asm volatile("" ::: "memory");
+        slot = slot == 2 ? 0 : slot + 1;
+        w0 = w1;
+        w1 = w2;
+        w2 = succ(w2, nw);
+    };
+    while (w0.pt < ntiles) {                                          // sub-positions alternate b = 0, 1
+        advance(std::integral_constant<int, 0>{});
+        advance(std::integral_constant<int, 1>{});
     }
 
     float* sd = slab_of<2, 4>(ws, jobs.j[4 + k], split);
@@ -247,7 +298,7 @@ __global__ __launch_bounds__(256, 1) void gblock_lean_branch_kernel(mgx_gblock_w
 // Staged per (tile, sub-position ab): rows 0-127 sum, rows 128-191 dt2.
 // ------------------------------------------------------------------------------------------
 constexpr int TL_ROWS = 192, TL_BUF = TL_ROWS * 64;
-constexpr int TL_LDS = 4 * 2 * TL_BUF;
+constexpr int TL_LDS = 4 * 3 * TL_BUF;
 
 __global__ __launch_bounds__(256, 1) void gblock_lean_tail_kernel(mgx_gblock_weights w, const bf16_t* __restrict__ act,
                                                                   const bf16_t* __restrict__ delta, GJobs jobs,
@@ -258,8 +309,9 @@ __global__ __launch_bounds__(256, 1) void gblock_lean_tail_kernel(mgx_gblock_wei
     const int lane = threadIdx.x & 63;
     const int wv = __builtin_amdgcn_readfirstlane(threadIdx.x >> 6);
     const int r = lane & 31, h = lane >> 5;
-    unsigned char* buf = lds + wv * (2 * TL_BUF);
+    unsigned char* buf = lds + wv * (3 * TL_BUF);
     const long split = (long)xb * 4 + wv, nw = (long)gridDim.x * 4;
+    using RM = GbRowsLean;
     const int c0 = 64 * q;
 
     // W1[in 128][out 256] as [in][c] of (channel tile uo, k-step); W2[c 256][out 64] as [out][c]
@@ -289,72 +341,94 @@ __global__ __launch_bounds__(256, 1) void gblock_lean_tail_kernel(mgx_gblock_wei
 #pragma unroll
         for (int u = 0; u < 2; ++u) splat(accW2[t][u], 0.f);
 
-    auto issue = [&](long t, int ab, int par) {
-        stage_rows<8>(act + (t * GB_ROWS + GB_S + ab * 128) * 32L, buf + par * TL_BUF, 0, lane);
-        stage_rows<4>(delta + (t * GB_ROWS + GB_T2 + ab * 64) * 32L, buf + par * TL_BUF, 128, lane);
+    const unsigned lbase = lds_addr(buf);
+    auto issue = [&](Walk wk, int slot) {
+        stage_rows<8>(act + (wk.pt * RM::ROWS + RM::S + wk.ab * 128) * 32L, lbase + slot * TL_BUF, 0, lane);
+        stage_rows<4>(delta + (wk.pt * RM::ROWS + RM::T2 + wk.ab * 64) * 32L, lbase + slot * TL_BUF, 128, lane);
     };
 
-    long pt = split;
-    int ab = 0, par = 0;
-    if (pt < ntiles) issue(pt, 0, 0);
-    while (pt < ntiles) {
-        long ptn = pt;
-        int abn = ab + 1;
-        if (abn == 4) { abn = 0; ptn = pt + nw; }
-        dma_wait();
-        if (ptn < ntiles) issue(ptn, abn, par ^ 1);
-        const unsigned char* cb = buf + par * TL_BUF;
-        // t1 of this quarter from sum (128 inputs), starting from the bias as the forward does
+    // three staging buffers: the rows of step i + 2 are requested before step i is computed
+    Walk w0 = {split, 0};
+    Walk w1 = succ(w0, nw), w2 = succ(w1, nw);
+    if (w0.pt < ntiles) issue(w0, 0);
+    if (w1.pt < ntiles) issue(w1, 1);
+    int slot = 0;
+    while (w0.pt < ntiles) {
+        const int s2 = slot == 0 ? 2 : slot - 1;                     // (slot + 2) % 3: read two steps ago
+        if (w2.pt < ntiles) issue(w2, s2);
+        dma_wait<12>((w1.pt < ntiles) + (w2.pt < ntiles));
+        const unsigned char* cb = buf + slot * TL_BUF;
+        // LDS reads run one group ahead of the MFMAs that consume them (all at once they would not fit the registers;
+        // the scheduling barriers keep the compiler from moving a group next to its consumers)
+        u32x4 as[8], at[4], asum[2][4], bt2[2][2];
+#pragma unroll
+        for (int s = 0; s < 4; ++s) at[s] = tr_frag(cb, 128 + 16 * s, lane);
+#pragma unroll
+        for (int s = 0; s < 4; ++s) as[s] = tr_frag(cb, 16 * s, lane);
+        __builtin_amdgcn_sched_barrier(0);
+        // dt1 of this quarter from dt2 (64 inputs); t1 of this quarter from sum (128 inputs), starting from the bias
+        // as the forward does.  Tiles of a pair advance together: no MFMA waits for the one before.
+        f32x16 t1[2], d1[2];
+#pragma unroll
+        for (int u = 0; u < 2; ++u) {
+            splat(t1[u], e1v[u]);
+            splat(d1[u], 0.f);
+        }
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+            for (int u = 0; u < 2; ++u) d1[u] = mfma_bf16(at[s], w2f[u][s], d1[u]);
+#pragma unroll
+        for (int s = 4; s < 8; ++s) as[s] = tr_frag(cb, 16 * s, lane);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int s = 0; s < 4; ++s)
+#pragma unroll
+            for (int u = 0; u < 2; ++u) t1[u] = mfma_bf16(as[s], w1f[u][s], t1[u]);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) asum[0][t] = perm_frag(cb, 32 * t + r, 0, h);
+#pragma unroll
+        for (int u = 0; u < 2; ++u) bt2[0][u] = perm_frag(cb, 128 + 32 * u + r, 0, h);
+        __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+        for (int s = 4; s < 8; ++s)
+#pragma unroll
+            for (int u = 0; u < 2; ++u) t1[u] = mfma_bf16(as[s], w1f[u][s], t1[u]);
+#pragma unroll
+        for (int t = 0; t < 4; ++t) asum[1][t] = perm_frag(cb, 32 * t + r, 1, h);
+#pragma unroll
+        for (int u = 0; u < 2; ++u) bt2[1][u] = perm_frag(cb, 128 + 32 * u + r, 1, h);
         u32x4 t1op[2][2], d1op[2][2];
-        {
-            u32x4 as[8];
 #pragma unroll
-            for (int s = 0; s < 8; ++s) as[s] = tr_frag(cb, 16 * s, lane);
+        for (int u = 0; u < 2; ++u) {
 #pragma unroll
-            for (int uo = 0; uo < 2; ++uo) {
-                f32x16 c;
-                splat(c, e1v[uo]);
-#pragma unroll
-                for (int s = 0; s < 8; ++s) c = mfma_bf16(as[s], w1f[uo][s], c);
-                t1op[uo][0] = to_op(c, 0);
-                t1op[uo][1] = to_op(c, 1);
-            }
+            for (int s = 0; s < 2; ++s) d1op[u][s] = to_op(d1[u], s);
+            bsE1[u] = add8(add8(bsE1[u], d1op[u][0]), d1op[u][1]);
         }
-        // dt1 of this quarter from dt2 (64 inputs)
-        {
-            u32x4 at[4];
+        __builtin_amdgcn_sched_barrier(0);
 #pragma unroll
-            for (int s = 0; s < 4; ++s) at[s] = tr_frag(cb, 128 + 16 * s, lane);
+        for (int s = 0; s < 2; ++s)
 #pragma unroll
-            for (int uo = 0; uo < 2; ++uo) {
-                f32x16 c;
-                splat(c, 0.f);
+            for (int t = 0; t < 4; ++t)
 #pragma unroll
-                for (int s = 0; s < 4; ++s) c = mfma_bf16(at[s], w2f[uo][s], c);
-                d1op[uo][0] = to_op(c, 0);
-                d1op[uo][1] = to_op(c, 1);
-                bsE1[uo] += sum8(d1op[uo][0]) + sum8(d1op[uo][1]);
-            }
-        }
+                for (int u = 0; u < 2; ++u) accW1[t][u] = mfma_bf16(asum[s][t], d1op[u][s], accW1[t][u]);
 #pragma unroll
-        for (int s = 0; s < 2; ++s) {
+        for (int u = 0; u < 2; ++u)
 #pragma unroll
-            for (int t = 0; t < 4; ++t) {
-                const u32x4 asum = perm_frag(cb, 32 * t + r, s, h);
+            for (int s = 0; s < 2; ++s) t1op[u][s] = to_op(t1[u], s);
 #pragma unroll
-                for (int u = 0; u < 2; ++u) accW1[t][u] = mfma_bf16(asum, d1op[u][s], accW1[t][u]);
-            }
+        for (int s = 0; s < 2; ++s)
 #pragma unroll
             for (int u = 0; u < 2; ++u) {
-                const u32x4 bt2 = perm_frag(cb, 128 + 32 * u + r, s, h);
-                bsE2[u] += sum8(bt2);
+                bsE2[u] = add8(bsE2[u], bt2[s][u]);
 #pragma unroll
-                for (int t = 0; t < 2; ++t) accW2[t][u] = mfma_bf16(t1op[t][s], bt2, accW2[t][u]);
+                for (int t = 0; t < 2; ++t) accW2[t][u] = mfma_bf16(t1op[t][s], bt2[s][u], accW2[t][u]);
             }
-        }
-        par ^= 1;
-        pt = ptn;
-        ab = abn;
+        asm volatile("" ::: "memory");
+        slot = slot == 2 ? 0 : slot + 1;
+        w0 = w1;
+        w1 = w2;
+        w2 = succ(w2, nw);
     }
 
     // W1 jobs (input half, output half) hold 2 x 4 tiles: this quarter is output tiles 2 (q & 1), 2 (q & 1) + 1 of

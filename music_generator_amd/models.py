@@ -354,7 +354,9 @@ def _register_fused_block(block_end, upsampling, for_sum_layer):
         w = weights()
         n, hl, wl, _ = x.shape
         bf = K.bf16_enabled()
-        side = ops.gblock_side_elems_bf16(n * hl * wl) if bf else ops.gblock_side_floats(n * hl * wl)
+        lean = bf and K.GBLOCK_LEAN_TAPE
+        side = (ops.gblock_side_elems_bf16_lean if lean else ops.gblock_side_elems_bf16)(n * hl * wl) if bf \
+            else ops.gblock_side_floats(n * hl * wl)
         budget = FusedGroup.side_budget_bytes
         side_bytes = (2 if bf else 4) * side
         if budget is None and side_bytes > FusedGroup.auto_budget_from_bytes:
@@ -364,7 +366,7 @@ def _register_fused_block(block_end, upsampling, for_sum_layer):
             # reference's batch of 2 needs 2 x 94 GiB in float32); otherwise bound both to 1/16 of the device
             # memory and re-compute.  Decided once per shape: a later call (the capture of a HIP graph after the
             # eager warm-up, say) must take the path whose scratch sizes the first one established.
-            key = ("bound", n, hl, wl, bf)
+            key = ("bound", n, hl, wl, bf, lean)
             if key not in state:
                 avail, total = K.available_bytes()
                 need = 2 * side_bytes + FusedGroup.reserve_bytes
@@ -374,26 +376,25 @@ def _register_fused_block(block_end, upsampling, for_sum_layer):
                 del FusedGroup.decisions[:-64]
             budget = state[key]
         if budget is not None and side_bytes > budget:
-            return run(x), (None, x, (n, hl, wl), bf, budget)
+            return run(x), (None, x, (n, hl, wl), bf, budget, lean)
         y = K.empty((n, 2 * hl, 2 * wl, 2))
         act = K.empty((side,), dtype=torch.bfloat16 if bf else torch.float32)
         if bf:
-            ops.gblock_fwd_bf16(w, packb(x), x, y, n, hl, wl, act=act, lean=K.GBLOCK_LEAN_TAPE)
+            ops.gblock_fwd_bf16(w, packb(x), x, y, n, hl, wl, act=act, lean=lean)
         else:
             ops.gblock_fwd(w, pack(), x, y, n, hl, wl, act=act)
-        return y, (act, None, (n, hl, wl), bf, None)
+        return y, (act, None, (n, hl, wl), bf, None, lean)
 
     def backward(saved, dy, need_weight_grads):
-        act, x, (n, hl, wl), bf, budget = saved
+        act, x, (n, hl, wl), bf, budget, lean = saved
         w = weights()
         key = ("packtb" if bf else "packt", K.current_lane())
         if key not in state:
             state[key] = torch.empty((ops.gblock_packt_bf16_bytes(),), dtype=torch.uint8, device=dy.device) if bf \
                 else K.empty((ops.gblock_packt_floats(),))
         packt = state[key]
-        # bf16: the tape is written without the four tensors the weight gradients recompute from their neighbours
-        # (K.GBLOCK_LEAN_TAPE); those kernels ignore the rows either way, so a tape written in full is accepted too
-        lean = bf and K.GBLOCK_LEAN_TAPE
+        # lean (bf16, K.GBLOCK_LEAN_TAPE when the tape was written): side buffers without the four tensors the
+        # weight-gradient kernels recompute from their neighbours
         fwd = (lambda **kw: ops.gblock_fwd_bf16(w, packb(dy), x, None, n, hl, wl, lean=lean, **kw)) if bf else \
               (lambda **kw: ops.gblock_fwd(w, pack(), x, None, n, hl, wl, **kw))
         if bf:
@@ -401,7 +402,7 @@ def _register_fused_block(block_end, upsampling, for_sum_layer):
             wgrad = lambda a, d, g, cnt: ops.gblock_wgrad_bf16(a, d, g, cnt, weights=w if lean else None)
         else:
             dgrad, wgrad = ops.gblock_dgrad, ops.gblock_wgrad
-        side_of = ops.gblock_side_elems_bf16 if bf else ops.gblock_side_floats
+        side_of = (ops.gblock_side_elems_bf16_lean if lean else ops.gblock_side_elems_bf16) if bf else ops.gblock_side_floats
         grads = None
         if need_weight_grads:
             for layer, _, _, _ in layer_fields:

@@ -821,10 +821,10 @@ def gblock_side_elems_bf16(npos) -> int:
     return int(_lib().mgx_gblock_side_elems_bf16(npos))
 
 
-# rows of a 32-position tile of a bf16 side buffer, and the ones the lean tape leaves unwritten (c2 / t1 and the
-# gradients that arrive at them: 6 x 4 x 64 + 4 x 256)
-GBLOCK_TILE_ROWS = 4104
-GBLOCK_LEAN_ROWS = GBLOCK_TILE_ROWS - 2560
+def gblock_side_elems_bf16_lean(npos) -> int:
+    """bf16 elements of a lean side buffer (no ConvT(64) / Dense(256) outputs and gradients): 1544 of 4104 rows."""
+    return int(_lib().mgx_gblock_side_elems_bf16_lean(npos))
+
 
 
 def gblock_fwd_bf16(weights, packb, x, y, nimg, hl, wl, act=None, pos0=0, npos=0, lean=False):
@@ -838,18 +838,17 @@ def gblock_fwd_bf16(weights, packb, x, y, nimg, hl, wl, act=None, pos0=0, npos=0
         raise MgxError("gblock_fwd_bf16: nothing to write")
     if y is not None and y.numel() != 4 * x.numel():
         raise MgxError("gblock_fwd_bf16: output size mismatch")
-    if act is not None and act.numel() < gblock_side_elems_bf16(n):
-        raise MgxError("gblock_fwd_bf16: activation buffer too small")
     lean = bool(lean and act is not None)
+    side = gblock_side_elems_bf16_lean(n) if lean else gblock_side_elems_bf16(n)
+    if act is not None and act.numel() < side:
+        raise MgxError("gblock_fwd_bf16: activation buffer too small")
     e0 = PROFILER.start() if PROFILER is not None else None
     fn = _lib().mgx_gblock_fwd_bf16_lean if lean else _lib().mgx_gblock_fwd_bf16
     check(fn(C.byref(weights), packb.data_ptr(), _p(x), _p(y), _pb(act), nimg, hl, wl, pos0, n, K.stream_ptr()),
           "mgx_gblock_fwd_bf16")
     if e0 is not None:
-        frac = GBLOCK_LEAN_ROWS / GBLOCK_TILE_ROWS if lean else 1.0
         PROFILER.stop("gblock_fwd_bf16_kernel<%s>" % ("true" if act is not None else "false"),
-                      GBLOCK_FLOP_PER_POSITION * n, e0,
-                      4.0 * 10 * n + (2.0 * frac * gblock_side_elems_bf16(n) if act is not None else 0))
+                      GBLOCK_FLOP_PER_POSITION * n, e0, 4.0 * 10 * n + (2.0 * side if act is not None else 0))
 
 
 def gblock_dgrad_bf16(weights, packt, dy, delta, dx, nimg, hl, wl, pos0=0, npos=0, lean=False):
@@ -857,22 +856,21 @@ def gblock_dgrad_bf16(weights, packt, dy, delta, dx, nimg, hl, wl, pos0=0, npos=
     if dx.numel() != nimg * hl * wl * 2 or dy.numel() != 4 * dx.numel() \
             or packt.numel() * packt.element_size() < gblock_packt_bf16_bytes():
         raise MgxError("gblock_dgrad_bf16: size mismatch")
-    if delta.numel() < gblock_side_elems_bf16(n):
+    side = gblock_side_elems_bf16_lean(n) if lean else gblock_side_elems_bf16(n)
+    if delta.numel() < side:
         raise MgxError("gblock_dgrad_bf16: gradient buffer too small")
     e0 = PROFILER.start() if PROFILER is not None else None
     fn = _lib().mgx_gblock_dgrad_bf16_lean if lean else _lib().mgx_gblock_dgrad_bf16
     check(fn(C.byref(weights), packt.data_ptr(), _p(dy), _pb(delta), _p(dx), nimg, hl, wl, pos0, n, K.stream_ptr()),
           "mgx_gblock_dgrad_bf16")
     if e0 is not None:
-        frac = GBLOCK_LEAN_ROWS / GBLOCK_TILE_ROWS if lean else 1.0
-        PROFILER.stop("gblock_dgrad_bf16_kernel", GBLOCK_FLOP_PER_POSITION * n, e0,
-                      4.0 * 10 * n + 2.0 * frac * gblock_side_elems_bf16(n))
+        PROFILER.stop("gblock_dgrad_bf16_kernel", GBLOCK_FLOP_PER_POSITION * n, e0, 4.0 * 10 * n + 2.0 * side)
 
 
 def gblock_wgrad_bf16(act, delta, grads, npos, weights=None):
     """Adds the block's 58 weight and bias gradients from the two side buffers.  With `weights` (the block's
-    variables, as the forward saw them) the operands the lean tape leaves out are recomputed."""
-    need = gblock_side_elems_bf16(npos)
+    variables, as the forward saw them) the buffers are lean ones and the operands they leave out are recomputed."""
+    need = gblock_side_elems_bf16_lean(npos) if weights is not None else gblock_side_elems_bf16(npos)
     if act.numel() < need or delta.numel() < need:
         raise MgxError("gblock_wgrad_bf16: side buffer too small")
     nbytes = int(_lib().mgx_gblock_wgrad_workspace_n(npos))
@@ -885,8 +883,7 @@ def gblock_wgrad_bf16(act, delta, grads, npos, weights=None):
         check(_lib().mgx_gblock_wgrad_bf16(_pb(act), _pb(delta), C.byref(grads), ws.data_ptr(), ws.numel(), npos,
                                            K.stream_ptr()), "mgx_gblock_wgrad_bf16")
     if e0 is not None:
-        frac = GBLOCK_LEAN_ROWS / GBLOCK_TILE_ROWS if weights is not None else 1.0
-        PROFILER.stop("gblock_wgrad_bf16_kernel<*>", GBLOCK_FLOP_PER_POSITION * npos, e0, 4.0 * frac * need)
+        PROFILER.stop("gblock_wgrad_bf16_kernel<*>", GBLOCK_FLOP_PER_POSITION * npos, e0, 4.0 * need)
 
 
 @_hbm_op("mul_bf16")

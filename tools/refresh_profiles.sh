@@ -5,7 +5,7 @@
 # counter passes (one rocprofv3 run each, counters only) aggregated per kernel.
 #   c2      stage 3 fade-in, batch 64, fp32 (the headline workload)
 #   c2bf16  the same step with bf16 storage / bf16 MFMA
-#   c3      the full-resolution step (stage 6, bf16, micro-batches of 4, 8 GiB generator tape) at batch 16: the
+#   c3      the full-resolution step (stage 6, bf16, micro-batches of 4, lean generator tape kept) at batch 16: the
 #           launches are those of the batch-256 step, 16 times fewer of them
 #   c5      generator-only inference at stage 6, bf16, chunks of 8
 set -e -o pipefail
@@ -17,7 +17,7 @@ mkdir -p "$out"
 case $mode in
   c2)     args="--no-extras --no-cpu-baseline"; pmc_args="--steps 1 --warmup 0 $args" ;;
   c2bf16) args="--precision bfloat16 --no-extras --no-cpu-baseline"; pmc_args="--steps 1 --warmup 0 $args" ;;
-  c3)     args="--stage 6 --batch 16 --micro-batch 4 --side-budget-gib 8 --precision bfloat16 --steps 1 --warmup 1 --no-extras --no-cpu-baseline"; pmc_args="$args --warmup 0" ;;
+  c3)     args="--stage 6 --batch 16 --micro-batch 4 --precision bfloat16 --steps 1 --warmup 1 --no-extras --no-cpu-baseline"; pmc_args="$args --warmup 0" ;;
   c5)     args="--infer --precision bfloat16 --clips 64"; pmc_args="--infer --precision bfloat16 --clips 16" ;;
   *) echo "unknown mode $mode"; exit 2 ;;
 esac
