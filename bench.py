@@ -229,6 +229,7 @@ T_START = time.perf_counter()
 
 
 C3_DIGEST = "r3_c3" if os.path.exists(os.path.join(ROOT, "profiles", "r3_c3_digest.json")) else "r2_c3"
+C2_DIGEST = "r3_c2" if os.path.exists(os.path.join(ROOT, "profiles", "r3_c2_digest.json")) else "r2_c2"
 C3_MICRO_BATCH = 4          # samples per micro-batch of the full-resolution step (whole MinibatchStdDev groups)
 
 
@@ -622,7 +623,7 @@ def main():
         roof["traffic"] = measured_traffic(key, wl)
         if (stage, fade, args.batch) == (3, True, 64):
             roof["mfma_busy_frac_sq_counters"] = measured_mfma_busy(key, "r2_c2bf16" if args.precision == "bfloat16"
-                                                                    else "r2_c2")
+                                                                    else C2_DIGEST)
         if key.startswith("wino3_") and roof["bound"] == "mfma":
             # the kernel's algorithm is Winograd F(2x2,3x3): `achieved` counts the multiply-adds it executes
             # (16 per 2x2 patch and channel pair); the same launches as a rate of direct-convolution FLOPs:
