@@ -132,6 +132,9 @@ PROTOTYPES = {
     "mgx_conv_chain_bf16": (_I, [_I64, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P]),
     "mgx_conv_wgrad_bf16_workspace": (_I64, [_DESC]),
     "mgx_conv_wgrad_bf16": (_I, [_DESC, _P, _P, _P, _P, _P, _I64, _P]),
+    "mgx_conv_bwd_bf16_supported": (_I, [_DESC]),
+    "mgx_conv_bwd_bf16_workspace": (_I64, [_DESC]),
+    "mgx_conv_bwd_bf16": (_I, [_DESC, _P, _P, _P, _P, _P, _P, C.c_float, _P, _I64, _P]),
     "mgx_pointwise2_bf16_fwd": (_I, [_P, _P, _P, _P, _P, _I64, _F, _P]),
     "mgx_pointwise2_bf16_wgrad_workspace": (_I64, [_I64]),
     "mgx_pointwise2_bf16_wgrad": (_I, [_P, _P, _P, _P, _P, _I64, _I64, _P]),

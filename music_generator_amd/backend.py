@@ -134,6 +134,9 @@ BF16_MIN_ROWS = 8
 # traffic in every taped forward.  True: the derivative is written as a bf16 tensor of its own by the forward
 # epilogue (one more rounding-exact value per element, twice the tape).
 BF16_SAVE_DERIVATIVE = False
+# bf16 32 -> 32 'same' convolutions whose backward needs both gradients: one kernel that reads the layer input and
+# the incoming gradient once (mgx_conv_bwd_bf16) instead of a data-gradient and a weight-gradient launch.
+BF16_FUSED_CONV_BACKWARD = os.environ.get("MGX_FUSED_CONV_BWD", "1") != "0"
 # bf16 generator grow blocks: leave the outputs of the Conv2DTranspose(64) / Dense(256) layers and the gradients
 # arriving at them off the tape (5120 of its 8138 rows per 32 positions); the weight-gradient kernels recompute
 # them from the neighbouring rows.  False: every tensor on the tape, every weight gradient read from it.

@@ -246,6 +246,248 @@ __global__ __launch_bounds__(1024) void bwgrad_reduce_kernel(mgx_conv_desc d, co
     }
 }
 
+// ------------------------------------------------------------------------------------------
+// Data gradient AND weight gradient of one 32 -> 32 'same' convolution in one pass (the two read the same two
+// tensors: the layer input X, which is also the stored output of the layer before it, and the gradient G with
+// respect to this layer's pre-activation):
+//     dW[tap][ci][co] += sum_q X[q][ci] G[q - tap + pad][co]          dB[co] += sum_q G[q][co]
+//     dX[q][ci]        = sum_tap sum_co W[tap][ci][co] G[q - tap + pad][co]     (x f'(X[q][ci]) when X is the output of a
+//                                                                               SoftRectifier layer: the gradient the
+//                                                                               layer before wants)
+// Both contract G shifted by the tap, so the G window (tile + halo) is staged once and serves both, and the X tile
+// serves the weight gradient (channel-major through ds_read_b64_tr_b16) and the activation derivative of the
+// epilogue: 128 B read + 64 B written per position instead of 192 + 128 + 64 for the two separate kernels.
+// Geometry of bwgrad_kernel: 4 waves, tiles of 8 rows x 64 columns, a wave owns two rows, one accumulator tile per
+// tap for the whole launch, plus one 32-position data-gradient tile at a time (D[ci][position]: the weights are the
+// A operand, a register fragment per tap and 16-channel step; the B operand is 16 bytes of a staged position).
+// Staged positions are 64 B with their four 16-byte chunks XOR-swizzled by bits 2-3 of the position index, which
+// keeps both kinds of read conflict-free.
+// ------------------------------------------------------------------------------------------
+template <int KH, int KW>
+struct FGeo {
+    static constexpr int TW = 64;
+    static constexpr int GH = WTH + KH - 1, GW = TW + KW - 1;
+    static constexpr int GPIX = GH * GW, XPIX = WTH * TW, TAPS = KH * KW;
+    static constexpr int LDS = 2 * (GPIX + XPIX) * 64;
+};
+
+__device__ __forceinline__ int sw_off(int p, int c16) { return p * 64 + ((c16 ^ ((p >> 2) & 3)) << 4); }
+
+template <int KH, int KW>
+__global__ __launch_bounds__(256, 1) void bbwd_kernel(mgx_conv_desc d, const bf16_t* __restrict__ x,
+                                                      const bf16_t* __restrict__ g, const float* __restrict__ w,
+                                                      bf16_t* __restrict__ dx, float* __restrict__ partial, long ntiles,
+                                                      int tiles_h, int tiles_w, float act_alpha) {
+    extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
+    using G = FGeo<KH, KW>;
+    constexpr int TW = G::TW, GW = G::GW, GPIX = G::GPIX, XPIX = G::XPIX, TAPS = G::TAPS;
+    constexpr int GITER = (GPIX * 4 + 255) / 256, XITER = (XPIX * 4 + 255) / 256;
+    const int tid = threadIdx.x, lane = tid & 63;
+    const int wvs = __builtin_amdgcn_readfirstlane(tid >> 6);
+    const int r = lane & 31, h = lane >> 5;
+    const int H = d.hin, W = d.win;
+    const int slot = blockIdx.x, nslots = gridDim.x;
+    constexpr int PT = (KH - 1) / 2, PL = (KW - 1) / 2;       // 'same' padding in front (Keras: the extra row of an even kernel goes behind)
+    constexpr int gy0 = KH - 1 - PT, gx0 = KW - 1 - PL;       // rows / columns of halo in front of the tile
+    unsigned char* gbuf = lds;                       // [2][GPIX][64 B]
+    unsigned char* xbuf = lds + 2 * GPIX * 64;       // [2][XPIX][64 B]
+
+    auto tile_of = [&](long t, long& img, int& h0, int& w0) {
+        const unsigned per_img = (unsigned)(tiles_h * tiles_w);
+        const unsigned tu = (unsigned)t;
+        const unsigned im = tu / per_img;
+        const unsigned rem = tu - im * per_img;
+        const unsigned th = rem / (unsigned)tiles_w;
+        img = im;
+        h0 = (int)th * WTH;
+        w0 = (int)(rem - th * tiles_w) * TW;
+    };
+    const int q4 = tid & 3;
+    u32x4 sg[GITER], sx[XITER];
+    auto stage_load = [&](long t) {
+        long img; int h0, w0;
+        tile_of(t, img, h0, w0);
+        const int hb = h0 - gy0, wb = w0 - gx0;
+        const long gband = ((img * H + hb) * (long)W) * 32;
+        const __amdgpu_buffer_rsrc_t rg =
+            __builtin_amdgcn_make_buffer_rsrc((void*)(g + gband), 0, (unsigned)G::GH * W * 64u, 0x00020000);
+#pragma unroll
+        for (int i = 0; i < GITER; ++i) {
+            const int px = (tid >> 2) + 64 * i;
+            const int ty = px / GW, tx = px - ty * GW;
+            const unsigned hi = (unsigned)(ty + hb), wi = (unsigned)(tx + wb);
+            const bool ok = px < GPIX && hi < (unsigned)H && wi < (unsigned)W;
+            const unsigned off = ok ? (unsigned)(((ty * W + (tx + wb)) * 32 + q4 * 8) * 2) : 0xfffffff0u;
+            sg[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rg, off, 0, 0));
+        }
+        const long xband = ((img * H + h0) * (long)W) * 32;
+        const __amdgpu_buffer_rsrc_t rx =
+            __builtin_amdgcn_make_buffer_rsrc((void*)(x + xband), 0, (unsigned)WTH * W * 64u, 0x00020000);
+#pragma unroll
+        for (int i = 0; i < XITER; ++i) {
+            const int px = (tid >> 2) + 64 * i;
+            const int ty = px / TW, tx = px - ty * TW;
+            const bool ok = (unsigned)(ty + h0) < (unsigned)H && (unsigned)(tx + w0) < (unsigned)W;
+            const unsigned off = ok ? (unsigned)(((ty * W + (tx + w0)) * 32 + q4 * 8) * 2) : 0xfffffff0u;
+            sx[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, off, 0, 0));
+        }
+    };
+    auto stage_write = [&](int b) {
+#pragma unroll
+        for (int i = 0; i < GITER; ++i) {
+            const int px = (tid >> 2) + 64 * i;
+            if (64 * (i + 1) <= GPIX || px < GPIX) *(u32x4*)(gbuf + b * GPIX * 64 + sw_off(px, q4)) = sg[i];
+        }
+#pragma unroll
+        for (int i = 0; i < XITER; ++i) {
+            const int px = (tid >> 2) + 64 * i;
+            *(u32x4*)(xbuf + b * XPIX * 64 + sw_off(px, q4)) = sx[i];
+        }
+    };
+
+    // weights W[tap][ci][co] (Keras layout, co fastest) as A fragments of the data gradient: lane (ci, h), k = co
+    u32x4 wf[TAPS][2];
+#pragma unroll
+    for (int tap = 0; tap < TAPS; ++tap)
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+            const float* p = w + tap * 1024 + r * 32 + 16 * ks + 8 * h;
+            const f32x4 a = *(const f32x4*)p, b = *(const f32x4*)(p + 4);
+            wf[tap][ks] = (u32x4){bf_pack(a[0], a[1]), bf_pack(a[2], a[3]), bf_pack(b[0], b[1]), bf_pack(b[2], b[3])};
+        }
+    const float inv_alpha = act_alpha > 0.f ? 1.0f / act_alpha : 0.f, k1 = 1.0f + inv_alpha;
+
+    f32x16 acc[TAPS + 1];
+#pragma unroll
+    for (int a = 0; a <= TAPS; ++a)
+#pragma unroll
+        for (int i = 0; i < 16; ++i) acc[a][i] = 0.f;
+    const u32x4 ones = {0x3f803f80u, 0x3f803f80u, 0x3f803f80u, 0x3f803f80u};
+
+    // transposed-read lane geometry (bwgrad_kernel): 16-lane group gq = lane >> 4 serves channel block gq & 1 and k
+    // half gq >> 1; lane 4q + p of a group supplies the address of position q, channels 4p .. 4p+3
+    const int hk = lane >> 5, cb = (lane >> 4) & 1, qq = (lane >> 2) & 3, pp = lane & 3;
+    const int col_l = 8 * hk + qq;
+    const int tr_c16 = 2 * cb + (pp >> 1), tr_half = 8 * (pp & 1);
+    auto tr_pair = [&](const unsigned char* buf, int p) {          // positions p .. p+3 and p+4 .. p+7 of the lane's channels
+        const u32x2 a0 = tr_read(buf + sw_off(p, tr_c16) + tr_half), a1 = tr_read(buf + sw_off(p + 4, tr_c16) + tr_half);
+        return (u32x4){a0[0], a0[1], a1[0], a1[1]};
+    };
+
+    long t = slot;
+    int cur = 0;
+    if (t < ntiles) {
+        stage_load(t);
+        stage_write(0);
+    }
+    __syncthreads();
+    while (t < ntiles) {
+        const long tn = t + nslots;
+        const bool has_next = tn < ntiles;
+        if (has_next) stage_load(tn);
+        long img; int h0, w0;
+        tile_of(t, img, h0, w0);
+        const unsigned char* gb = gbuf + cur * GPIX * 64;
+        const unsigned char* xb = xbuf + cur * XPIX * 64;
+#pragma unroll 1
+        for (int rr = 0; rr < 2; ++rr) {
+            const int wr = 2 * wvs + rr;
+#pragma unroll 1
+            for (int cg = 0; cg < 2; ++cg) {
+                const int col0 = 32 * cg;
+                // ---- data gradient of positions (wr, col0 .. col0 + 31): D[ci][position] ----
+                f32x16 dacc;
+#pragma unroll
+                for (int i = 0; i < 16; ++i) dacc[i] = 0.f;
+#pragma unroll
+                for (int tap = 0; tap < TAPS; ++tap) {
+                    const int ta = tap / KW, tb = tap - ta * KW;
+                    const int p = (wr + KH - 1 - ta) * GW + col0 + r + KW - 1 - tb;
+#pragma unroll
+                    for (int ks = 0; ks < 2; ++ks)
+                        dacc = mfma_bf16(wf[tap][ks], *(const u32x4*)(gb + sw_off(p, 2 * ks + h)), dacc);
+                }
+                // the data-gradient MFMAs stay in front of the weight-gradient ones: the exchange of the epilogue
+                // (inline assembly) then reads a tile whose last MFMA lies 20 MFMAs back
+                __builtin_amdgcn_sched_barrier(0);
+                // ---- weight gradient over the same 32 positions: two k-steps of 16 ----
+#pragma unroll
+                for (int ks = 0; ks < 2; ++ks) {
+                    const int col = col0 + 16 * ks + col_l;
+                    const u32x4 afrag = tr_pair(xb, wr * TW + col);
+#pragma unroll
+                    for (int tap = 0; tap < TAPS; ++tap) {
+                        const int ta = tap / KW, tb = tap - ta * KW;
+                        const u32x4 bfrag = tr_pair(gb, (wr + KH - 1 - ta) * GW + col + KW - 1 - tb);
+                        acc[tap] = mfma_bf16(afrag, bfrag, acc[tap]);
+                        if (ta == PT && tb == PL) acc[TAPS] = mfma_bf16(ones, bfrag, acc[TAPS]);     // the unshifted window
+                    }
+                }
+                __builtin_amdgcn_sched_barrier(0);
+                // ---- epilogue: x f'(X) where the layer before is a SoftRectifier layer, bf16, 2 x 16 B a lane ----
+                acc_rows_interleaved(dacc);          // lane (position r, h): channels 8h .. 8h+7 and 16+8h .. 16+8h+7
+                const int px = wr * TW + col0 + r;
+                u32x4 o[2];
+#pragma unroll
+                for (int half = 0; half < 2; ++half) {
+                    const u32x4 yv = *(const u32x4*)(xb + sw_off(px, 2 * half + h));
+#pragma unroll
+                    for (int q = 0; q < 4; ++q) {
+                        float v0 = dacc[8 * half + 2 * q], v1 = dacc[8 * half + 2 * q + 1];
+                        if (act_alpha > 0.f) {
+                            v0 *= dact_from_y(bf_lo(yv[q]), inv_alpha, k1);
+                            v1 *= dact_from_y(bf_hi(yv[q]), inv_alpha, k1);
+                        }
+                        o[half][q] = bf_pack(v0, v1);
+                    }
+                }
+                const int oh = h0 + wr, ow = w0 + col0 + r;
+                if (oh < H && ow < W) {
+                    bf16_t* dst = dx + (((img * H + oh) * (long)W + ow) * 32);
+                    *(u32x4*)(dst + 8 * h) = o[0];
+                    *(u32x4*)(dst + 16 + 8 * h) = o[1];
+                }
+            }
+        }
+        if (has_next) stage_write(cur ^ 1);
+        __syncthreads();
+        cur ^= 1;
+        t = tn;
+    }
+
+    // ---- add the four waves in fixed order: (w0 + w2) + (w1 + w3), through LDS ----
+    float* red = (float*)lds;                           // [2][TAPS+1][16][64] floats <= 80 KB
+    __syncthreads();
+    if (wvs >= 2) {
+#pragma unroll
+        for (int a = 0; a <= TAPS; ++a)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) red[(((wvs - 2) * (TAPS + 1) + a) * 16 + i) * 64 + lane] = acc[a][i];
+    }
+    __syncthreads();
+    if (wvs < 2) {
+#pragma unroll
+        for (int a = 0; a <= TAPS; ++a)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) acc[a][i] += red[((wvs * (TAPS + 1) + a) * 16 + i) * 64 + lane];
+    }
+    __syncthreads();
+    if (wvs == 1) {
+#pragma unroll
+        for (int a = 0; a <= TAPS; ++a)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) red[(a * 16 + i) * 64 + lane] = acc[a][i];
+    }
+    __syncthreads();
+    if (wvs == 0) {
+        float* dst = partial + ((long)slot * (TAPS + 1)) * 1024;
+#pragma unroll
+        for (int a = 0; a <= TAPS; ++a)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) dst[(a * 16 + i) * 64 + lane] = acc[a][i] + red[(a * 16 + i) * 64 + lane];
+    }
+}
+
 constexpr int WGRID = 256;
 
 template <int KH, int KW, bool S2>
@@ -269,6 +511,24 @@ int launch_w(const mgx_conv_desc& d, const bf16_t* x, const bf16_t* g, float* dw
 }
 
 int wgrad_taps(const mgx_conv_desc& d) { return d.kh * d.kw; }
+
+template <int KH, int KW>
+int launch_f(const mgx_conv_desc& d, const bf16_t* x, const bf16_t* g, const float* w, float* dw, float* db, bf16_t* dx,
+             float* partial, float act_alpha, hipStream_t st) {
+    using G = FGeo<KH, KW>;
+    const int tiles_h = (d.hout + WTH - 1) / WTH, tiles_w = (d.wout + G::TW - 1) / G::TW;
+    const long ntiles = (long)d.nimg * tiles_h * tiles_w;
+    if (ntiles <= 0 || ntiles >= (1L << 31)) return MGX_ERR_ARG;
+    if (hipFuncSetAttribute((const void*)bbwd_kernel<KH, KW>, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS) !=
+        hipSuccess)
+        return MGX_ERR_LAUNCH;
+    hipLaunchKernelGGL((bbwd_kernel<KH, KW>), dim3(WGRID), dim3(256), G::LDS, st, d, x, g, w, dx, partial, ntiles, tiles_h,
+                       tiles_w, act_alpha);
+    const long total = (long)G::TAPS * 1024 + (db ? d.ngemm : 0);
+    hipLaunchKernelGGL(bwgrad_reduce_kernel, dim3((unsigned)((total + 63) / 64)), dim3(1024), 0, st, d, partial, dw, db,
+                       WGRID, 1, G::TAPS);
+    return mgx_launch_status();
+}
 
 }  // namespace
 
@@ -296,4 +556,32 @@ extern "C" int mgx_conv_wgrad_bf16(const mgx_conv_desc* dp, const void* x, const
     if (d.kh == 3) return launch_w<3, 3, false>(d, xb, gb, dw, dbias, part, st);
     if (d.kh == 2) return launch_w<2, 2, false>(d, xb, gb, dw, dbias, part, st);
     return launch_w<1, 1, false>(d, xb, gb, dw, dbias, part, st);
+}
+
+// The fused backward serves the 3x3 and 2x2 'same' convolutions between 32 and 32 channels, stride 1, weights in
+// the Keras layout of the forward descriptor (tap, input channel, output channel; output channel fastest).
+extern "C" int mgx_conv_bwd_bf16_supported(const mgx_conv_desc* d) {
+    if (!d || !mgx_conv_bf16_supported(d)) return 0;
+    if (d->cin != 32 || d->ngemm != 32 || d->cout != 32 || d->sh != 1 || d->sw != 1 || d->dkh != 1 || d->dkw != 1 || d->flip)
+        return 0;
+    if (!((d->kh == 3 && d->kw == 3) || (d->kh == 2 && d->kw == 2))) return 0;
+    if (d->hin != d->hout || d->win != d->wout || d->pt != (d->kh - 1) / 2 || d->pl != (d->kw - 1) / 2) return 0;
+    return d->wsn == 1 && d->wsk == 32 && d->wtap == 1024;
+}
+
+extern "C" int64_t mgx_conv_bwd_bf16_workspace(const mgx_conv_desc* d) {
+    return mgx_conv_bwd_bf16_supported(d) ? mgx_conv_wgrad_bf16_workspace(d) : 0;
+}
+
+extern "C" int mgx_conv_bwd_bf16(const mgx_conv_desc* dp, const void* x, const void* g, const float* w, float* dw,
+                                 float* dbias, void* dx, float act_alpha, void* workspace, int64_t workspace_bytes,
+                                 void* stream) {
+    if (!dp || !x || !g || !w || !dw || !dx || !workspace || !mgx_conv_bwd_bf16_supported(dp)) return MGX_ERR_ARG;
+    if (workspace_bytes < mgx_conv_bwd_bf16_workspace(dp)) return MGX_ERR_WORKSPACE;
+    if (dbias && dp->nbias != dp->ngemm) return MGX_ERR_ARG;
+    if (!(act_alpha >= 0.f)) return MGX_ERR_ARG;
+    hipStream_t st = (hipStream_t)stream;
+    if (dp->kh == 3)
+        return launch_f<3, 3>(*dp, (const bf16_t*)x, (const bf16_t*)g, w, dw, dbias, (bf16_t*)dx, (float*)workspace, act_alpha, st);
+    return launch_f<2, 2>(*dp, (const bf16_t*)x, (const bf16_t*)g, w, dw, dbias, (bf16_t*)dx, (float*)workspace, act_alpha, st);
 }

@@ -335,9 +335,16 @@ bool mgx_pointwise2_applicable(const mgx_conv_desc& d) { return pointwise2_appli
 
 namespace {
 
+// The value of another lane of the same 16-lane row, chosen by a DPP control word (a vector ALU move, no LDS
+// crossbar round trip).
+template <int CTRL>
+__device__ __forceinline__ float row_lane(float v) {
+    return __int_as_float(__builtin_amdgcn_update_dpp(0, __float_as_int(v), CTRL, 0xf, 0xf, true));
+}
+
 // 1x1 convolution to 2 output channels (the data-gradient of the from-audio layers): two dot
 // products per position over C = 4 q input channels, read once at the HBM rate.  q lanes share a
-// position (16 bytes each, optionally times the multiplier), reduce with shuffles, lane 0 stores.
+// position (16 bytes each, optionally times the multiplier), reduce across lanes, lane 0 stores.
 template <bool MUL>
 __global__ __launch_bounds__(256) void pointwise_to2_kernel(const float* __restrict__ x,
                                                             const float* __restrict__ xmul,
@@ -367,10 +374,16 @@ __global__ __launch_bounds__(256) void pointwise_to2_kernel(const float* __restr
         }
         float s0 = v[0] * w0[0] + v[1] * w0[1] + v[2] * w0[2] + v[3] * w0[3];
         float s1 = v[0] * w1[0] + v[1] * w1[1] + v[2] * w1[2] + v[3] * w1[3];
-        for (int o = q >> 1; o > 0; o >>= 1) {
-            s0 += __shfl_xor(s0, o, 64);
-            s1 += __shfl_xor(s1, o, 64);
-        }
+        // Sum over the q lanes of a position.  Lanes of one 16-lane row exchange through the vector ALU's own
+        // lane crossbar (quad permutes, then mirrors: after the quad steps every lane of a quad holds the quad's
+        // sum, so the mirrored lane supplies the other quad's / half's sum); only the two widest steps go through
+        // the LDS crossbar, with offsets known at compile time.
+        if (q > 1) { s0 += row_lane<0xB1>(s0); s1 += row_lane<0xB1>(s1); }     // quad_perm [1,0,3,2]
+        if (q > 2) { s0 += row_lane<0x4E>(s0); s1 += row_lane<0x4E>(s1); }     // quad_perm [2,3,0,1]
+        if (q > 4) { s0 += row_lane<0x141>(s0); s1 += row_lane<0x141>(s1); }   // row_half_mirror
+        if (q > 8) { s0 += row_lane<0x140>(s0); s1 += row_lane<0x140>(s1); }   // row_mirror
+        if (q > 16) { s0 += __shfl_xor(s0, 16, 64); s1 += __shfl_xor(s1, 16, 64); }
+        if (q > 32) { s0 += __shfl_xor(s0, 32, 64); s1 += __shfl_xor(s1, 32, 64); }
         if (ok && c == 0) *(float2*)(y + p * 2) = make_float2(s0 + b0, s1 + b1);
     }
 }

@@ -172,8 +172,11 @@ class _Contraction(Layer):
             dx = existing[0] if existing[0] is not None else K.empty(x.shape)
             ops.pointwise_to2_bf16(g, self.kernel.value(), dx, n * h * w, existing[0] is not None)
             return [(dx, True)]
-        if do_w:
-            ops.conv_wgrad_bf16(self._desc("f", n, h, w), x, g, self.kernel.grad, self.bias.grad)
+        fdesc = self._desc("f", n, h, w)
+        fuse = do_w and need[0] and existing[0] is None and K.BF16_FUSED_CONV_BACKWARD \
+            and (outmul is None or outmul.dact is None) and ops.conv_bwd_bf16_supported(fdesc)
+        if do_w and not fuse:
+            ops.conv_wgrad_bf16(fdesc, x, g, self.kernel.grad, self.bias.grad)
         if not need[0]:
             return [None]
         if existing[0] is not None:
@@ -184,7 +187,12 @@ class _Contraction(Layer):
             # the stored derivative, or the producer's stored output (= this layer's input) it is recovered from
             ymul, mul_alpha = (outmul.dact, 0.0) if outmul.dact is not None else (outmul.yact, outmul.alpha)
             outmul.premultiplied = True      # the producer of x receives dX (.) f' and must not multiply again
-        ops.conv_gemm_bf16(self._desc("d", n, h, w), g, self.kernel.value(), None, dx, ymul=ymul, act_alpha=mul_alpha)
+        if fuse:
+            # both gradients read x and g: one pass (x is the producer's stored output the derivative comes from)
+            assert ymul is None or ymul is x
+            ops.conv_bwd_bf16(fdesc, x, g, self.kernel.value(), self.kernel.grad, self.bias.grad, dx, mul_alpha)
+        else:
+            ops.conv_gemm_bf16(self._desc("d", n, h, w), g, self.kernel.value(), None, dx, ymul=ymul, act_alpha=mul_alpha)
         return [(dx, True)]
 
 

@@ -751,6 +751,31 @@ def conv_wgrad_bf16(d: ConvDesc, x, g, dw, dbias):
         PROFILER.stop("bwgrad_kernel<%d,%d>" % (d.kh, d.kw), _conv_flops(d), e0, _conv_bytes_bf16(d, 1, 1))
 
 
+def conv_bwd_bf16_supported(d: ConvDesc) -> bool:
+    return bool(_lib().mgx_conv_bwd_bf16_supported(C.byref(d)))
+
+
+def conv_bwd_bf16(d: ConvDesc, x, g, w, dw, dbias, dx, act_alpha=0.0):
+    """Input gradient and weight / bias gradient of a bf16 32 -> 32 'same' convolution in one pass over x (the layer
+    input) and g (the gradient with respect to its pre-activation); d is the FORWARD descriptor.  dx is multiplied by
+    the activation derivative recovered from x when act_alpha > 0; dw / dbias are added to."""
+    xe, ye, we = _conv_sizes(d)
+    if x.numel() != xe or g.numel() != ye or dw.numel() < we or w.numel() < we or dx.numel() != xe:
+        raise MgxError("conv_bwd_bf16: operand sizes do not match the descriptor")
+    if dbias is not None and dbias.numel() != d.nbias:
+        raise MgxError("conv_bwd_bf16: bias gradient size mismatch")
+    lib = _lib()
+    nbytes = lib.mgx_conv_bwd_bf16_workspace(C.byref(d))
+    if nbytes <= 0:
+        raise MgxError("conv_bwd_bf16: unsupported descriptor")
+    ws = K.workspace(nbytes)
+    e0 = PROFILER.start() if PROFILER is not None else None
+    check(lib.mgx_conv_bwd_bf16(C.byref(d), _pb(x), _pb(g), _p(w), _p(dw), _p(dbias), _pb(dx), float(act_alpha),
+                                ws.data_ptr(), ws.numel(), K.stream_ptr()), "mgx_conv_bwd_bf16")
+    if e0 is not None:
+        PROFILER.stop("bbwd_kernel<%d,%d>" % (d.kh, d.kw), 2 * _conv_flops(d), e0, _conv_bytes_bf16(d, 2, 1))
+
+
 @_hbm_op("pointwise2_bf16_fwd")
 def pointwise2_bf16_fwd(x, w, bias, y, dact, npos, act_alpha):
     if x.numel() != 2 * npos or y.numel() != 128 * npos or w.numel() != 256 or (bias is not None and bias.numel() != 128) \
