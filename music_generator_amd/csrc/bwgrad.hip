@@ -17,6 +17,7 @@
 // At the end the four waves are added in LDS in fixed order, every workgroup leaves one slab in the
 // workspace, and a second kernel adds the slabs in fixed order into dW / dB (bitwise reproducible).
 #include "bf16.h"
+#include <type_traits>
 #include "../../include/mgx.h"
 
 namespace {
@@ -263,6 +264,15 @@ __global__ __launch_bounds__(1024) void bwgrad_reduce_kernel(mgx_conv_desc d, co
 // Staged positions are 64 B with their four 16-byte chunks XOR-swizzled by bits 2-3 of the position index, which
 // keeps both kinds of read conflict-free.
 // ------------------------------------------------------------------------------------------
+// compile-time unrolled loop: f(integral_constant<int, I>) for I in [I0, N)
+template <int I, int N, typename F>
+__device__ __forceinline__ void static_for(F&& f) {
+    if constexpr (I < N) {
+        f(std::integral_constant<int, I>{});
+        static_for<I + 1, N>(f);
+    }
+}
+
 template <int KH, int KW>
 struct FGeo {
     static constexpr int TW = 64;
@@ -273,7 +283,7 @@ struct FGeo {
 
 __device__ __forceinline__ int sw_off(int p, int c16) { return p * 64 + ((c16 ^ ((p >> 2) & 3)) << 4); }
 
-template <int KH, int KW>
+template <int KH, int KW, bool ACT>
 __global__ __launch_bounds__(256, 1) void bbwd_kernel(mgx_conv_desc d, const bf16_t* __restrict__ x,
                                                       const bf16_t* __restrict__ g, const float* __restrict__ w,
                                                       bf16_t* __restrict__ dx, float* __restrict__ partial, long ntiles,
@@ -282,6 +292,10 @@ __global__ __launch_bounds__(256, 1) void bbwd_kernel(mgx_conv_desc d, const bf1
     using G = FGeo<KH, KW>;
     constexpr int TW = G::TW, GW = G::GW, GPIX = G::GPIX, XPIX = G::XPIX, TAPS = G::TAPS;
     constexpr int GITER = (GPIX * 4 + 255) / 256, XITER = (XPIX * 4 + 255) / 256;
+    // A staged row of the G window is GW positions of 64 B; the swizzle of a position's four 16-byte chunks is keyed by
+    // its COLUMN (bits 2-3), so a read's address is a per-lane column term (computed once for the launch) plus a
+    // term that is uniform over the wave (buffer, row, 32-column block) plus a constant (kernel row, k-step).
+    constexpr int ROWB = GW * 64;
     const int tid = threadIdx.x, lane = tid & 63;
     const int wvs = __builtin_amdgcn_readfirstlane(tid >> 6);
     const int r = lane & 31, h = lane >> 5;
@@ -336,7 +350,8 @@ __global__ __launch_bounds__(256, 1) void bbwd_kernel(mgx_conv_desc d, const bf1
 #pragma unroll
         for (int i = 0; i < GITER; ++i) {
             const int px = (tid >> 2) + 64 * i;
-            if (64 * (i + 1) <= GPIX || px < GPIX) *(u32x4*)(gbuf + b * GPIX * 64 + sw_off(px, q4)) = sg[i];
+            const int ty = px / GW, tx = px - ty * GW;
+            if (64 * (i + 1) <= GPIX || px < GPIX) *(u32x4*)(gbuf + b * GPIX * 64 + ty * ROWB + sw_off(tx, q4)) = sg[i];
         }
 #pragma unroll
         for (int i = 0; i < XITER; ++i) {
@@ -368,9 +383,22 @@ __global__ __launch_bounds__(256, 1) void bbwd_kernel(mgx_conv_desc d, const bf1
     // half gq >> 1; lane 4q + p of a group supplies the address of position q, channels 4p .. 4p+3
     const int hk = lane >> 5, cb = (lane >> 4) & 1, qq = (lane >> 2) & 3, pp = lane & 3;
     const int col_l = 8 * hk + qq;
-    const int tr_c16 = 2 * cb + (pp >> 1), tr_half = 8 * (pp & 1);
-    auto tr_pair = [&](const unsigned char* buf, int p) {          // positions p .. p+3 and p+4 .. p+7 of the lane's channels
-        const u32x2 a0 = tr_read(buf + sw_off(p, tr_c16) + tr_half), a1 = tr_read(buf + sw_off(p + 4, tr_c16) + tr_half);
+    const int tr_k = 2 * cb + (pp >> 1), tr_h = 8 * (pp & 1);
+    int dB[KW][2], wB[KW][2], xB[2], yB[2];          // per-lane column terms: data-gradient operand, transposed G / X reads, epilogue
+#pragma unroll
+    for (int tb = 0; tb < KW; ++tb) {
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) dB[tb][ks] = sw_off(r + KW - 1 - tb, 2 * ks + h);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) wB[tb][j] = sw_off(col_l + KW - 1 - tb + 4 * j, tr_k) + tr_h;
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+        xB[j] = sw_off(col_l + 4 * j, tr_k) + tr_h;
+        yB[j] = sw_off(r, 2 * j + h);
+    }
+    auto tr_two = [&](const unsigned char* p0, const unsigned char* p1, int off) {     // positions c .. c+3 and c+4 .. c+7 of the lane's channels
+        const u32x2 a0 = tr_read(p0 + off), a1 = tr_read(p1 + off);
         return (u32x4){a0[0], a0[1], a1[0], a1[1]};
     };
 
@@ -387,67 +415,109 @@ __global__ __launch_bounds__(256, 1) void bbwd_kernel(mgx_conv_desc d, const bf1
         if (has_next) stage_load(tn);
         long img; int h0, w0;
         tile_of(t, img, h0, w0);
-        const unsigned char* gb = gbuf + cur * GPIX * 64;
-        const unsigned char* xb = xbuf + cur * XPIX * 64;
-#pragma unroll 1
-        for (int rr = 0; rr < 2; ++rr) {
-            const int wr = 2 * wvs + rr;
-#pragma unroll 1
-            for (int cg = 0; cg < 2; ++cg) {
-                const int col0 = 32 * cg;
-                // ---- data gradient of positions (wr, col0 .. col0 + 31): D[ci][position] ----
-                f32x16 dacc;
-#pragma unroll
-                for (int i = 0; i < 16; ++i) dacc[i] = 0.f;
-#pragma unroll
-                for (int tap = 0; tap < TAPS; ++tap) {
-                    const int ta = tap / KW, tb = tap - ta * KW;
-                    const int p = (wr + KH - 1 - ta) * GW + col0 + r + KW - 1 - tb;
-#pragma unroll
-                    for (int ks = 0; ks < 2; ++ks)
-                        dacc = mfma_bf16(wf[tap][ks], *(const u32x4*)(gb + sw_off(p, 2 * ks + h)), dacc);
-                }
-                // the data-gradient MFMAs stay in front of the weight-gradient ones: the exchange of the epilogue
-                // (inline assembly) then reads a tile whose last MFMA lies 20 MFMAs back
-                __builtin_amdgcn_sched_barrier(0);
-                // ---- weight gradient over the same 32 positions: two k-steps of 16 ----
-#pragma unroll
-                for (int ks = 0; ks < 2; ++ks) {
-                    const int col = col0 + 16 * ks + col_l;
-                    const u32x4 afrag = tr_pair(xb, wr * TW + col);
-#pragma unroll
-                    for (int tap = 0; tap < TAPS; ++tap) {
-                        const int ta = tap / KW, tb = tap - ta * KW;
-                        const u32x4 bfrag = tr_pair(gb, (wr + KH - 1 - ta) * GW + col + KW - 1 - tb);
-                        acc[tap] = mfma_bf16(afrag, bfrag, acc[tap]);
-                        if (ta == PT && tb == PL) acc[TAPS] = mfma_bf16(ones, bfrag, acc[TAPS]);     // the unshifted window
-                    }
-                }
-                __builtin_amdgcn_sched_barrier(0);
-                // ---- epilogue: x f'(X) where the layer before is a SoftRectifier layer, bf16, 2 x 16 B a lane ----
-                acc_rows_interleaved(dacc);          // lane (position r, h): channels 8h .. 8h+7 and 16+8h .. 16+8h+7
-                const int px = wr * TW + col0 + r;
-                u32x4 o[2];
-#pragma unroll
-                for (int half = 0; half < 2; ++half) {
-                    const u32x4 yv = *(const u32x4*)(xb + sw_off(px, 2 * half + h));
-#pragma unroll
-                    for (int q = 0; q < 4; ++q) {
-                        float v0 = dacc[8 * half + 2 * q], v1 = dacc[8 * half + 2 * q + 1];
-                        if (act_alpha > 0.f) {
-                            v0 *= dact_from_y(bf_lo(yv[q]), inv_alpha, k1);
-                            v1 *= dact_from_y(bf_hi(yv[q]), inv_alpha, k1);
-                        }
-                        o[half][q] = bf_pack(v0, v1);
-                    }
-                }
-                const int oh = h0 + wr, ow = w0 + col0 + r;
-                if (oh < H && ow < W) {
-                    bf16_t* dst = dx + (((img * H + oh) * (long)W + ow) * 32);
-                    *(u32x4*)(dst + 8 * h) = o[0];
-                    *(u32x4*)(dst + 16 + 8 * h) = o[1];
+        // One 32-position block at a time (row wr, columns col0 .. col0 + 31), its MFMAs in stages of one kernel row:
+        // KH stages of the data gradient, then 2 KH of the weight gradient.  One wave per SIMD, so nothing but this
+        // wave's own instruction order overlaps LDS latency, vector ALU work and the matrix unit: the LDS reads that
+        // prepare stage s + 1 are issued between the MFMAs of stage s (the first stage of the next block between
+        // the last MFMAs of this one), and the epilogue of the block's data gradient (lane exchange, activation
+        // derivative, rounding, stores) in pieces between the MFMAs of its weight gradient.  The scheduling barriers
+        // pin that order.
+        const int ugb = cur * GPIX * 64, uxb = (2 * GPIX + cur * XPIX) * 64;        // uniform terms of the current buffers
+        constexpr int NJ = 2 * KW, NSTAGE = 3 * KH, NWM = 2 * (TAPS + 1), NPIECE = 19, WM0 = 2;
+        u32x4 dq[2][NJ], wq[2][KW], af[2], yv[2], o[2];
+        f32x16 dacc;
+        int ug = ugb + 2 * wvs * ROWB, ux = 0, ugn = ug, oh = 0, ow = 0;
+        // item I of the LDS reads that stage S works on (S = NSTAGE: stage 0 of the next block)
+        auto prep = [&](auto S_, auto I_) {
+            constexpr int S = decltype(S_)::value, i = decltype(I_)::value;
+            if constexpr (S < KH || S >= NSTAGE) {
+                constexpr int ta = S < KH ? S : 0, tb = i >> 1, ks = i & 1;
+                dq[ta & 1][i] = *(const u32x4*)(lds + (dB[tb][ks] + (S < KH ? ug : ugn)) + (KH - 1 - ta) * ROWB);
+            } else {
+                constexpr int st = S - KH, ks = st / KH, ta = st - ks * KH, first = ta == 0 ? 1 : 0;
+                if constexpr (first == 1 && i == 0) {
+                    af[ks & 1] = tr_two(lds + (xB[0] + ux), lds + (xB[1] + ux), 16 * ks * 64);
+                } else {
+                    constexpr int tb = i - first;
+                    wq[st & 1][tb] = tr_two(lds + (wB[tb][0] + ug), lds + (wB[tb][1] + ug), (KH - 1 - ta) * ROWB + 16 * ks * 64);
                 }
             }
+        };
+        // piece I of the epilogue of the block's data gradient
+        auto piece = [&](auto I_) {
+            constexpr int i = decltype(I_)::value;
+            if constexpr (i < 8) {
+                // lane exchange (acc_rows_interleaved, one swap a piece): lane (position r, h) ends up with channels
+                // 8h .. 8h+7 in dacc[0..7] and 16+8h .. 16+8h+7 in dacc[8..15]
+                constexpr int g = i >> 2, e = i & 3;
+                float lo = dacc[8 * g + e], hi = dacc[8 * g + 4 + e];
+                asm volatile("s_nop 1\n\tv_permlane32_swap_b32 %0, %1" : "+v"(lo), "+v"(hi));
+                dacc[8 * g + e] = lo;
+                dacc[8 * g + 4 + e] = hi;
+            } else if constexpr (i == 8) {
+                yv[0] = *(const u32x4*)(lds + (yB[0] + ux));
+                yv[1] = *(const u32x4*)(lds + (yB[1] + ux));
+            } else {
+                constexpr int half = (i - 9) / 5, q = (i - 9) - 5 * half;
+                if constexpr (q < 4) {
+                    float v0 = dacc[8 * half + 2 * q], v1 = dacc[8 * half + 2 * q + 1];
+                    if constexpr (ACT) {     // x f'(X): the layer before is a SoftRectifier layer and X its stored output
+                        v0 *= dact_from_y(bf_lo(yv[half][q]), inv_alpha, k1);
+                        v1 *= dact_from_y(bf_hi(yv[half][q]), inv_alpha, k1);
+                    }
+                    o[half][q] = bf_pack(v0, v1);
+                } else if (oh < H && ow < W) {
+                    bf16_t* dst = dx + (((img * H + oh) * (long)W + ow) * 32);
+                    *(u32x4*)(dst + 16 * half + 8 * h) = o[half];
+                }
+            }
+        };
+        // MFMA M of stage S (the centre tap's second one sums the unshifted window for the bias gradient), with the
+        // reads and epilogue pieces that go around it
+        auto step = [&](auto S_, auto M_) {
+            constexpr int S = decltype(S_)::value, m = decltype(M_)::value;
+            constexpr bool dstage = S < KH;
+            constexpr int st = dstage ? 0 : S - KH, ks = st / KH, ta = dstage ? S : st - ks * KH;
+            constexpr int nm = dstage ? NJ : KW + (ta == PT ? 1 : 0);
+            constexpr int nl = (S + 1 < KH || S + 1 >= NSTAGE) ? NJ : KW + ((S + 1 - KH) % KH == 0 ? 1 : 0);
+            constexpr int l0 = (m * nl + nm - 1) / nm, l1 = ((m + 1) * nl + nm - 1) / nm;
+            static_for<l0, l1>([&](auto I_) { prep(std::integral_constant<int, S + 1>{}, I_); });
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (dstage) {
+                dacc = mfma_bf16(wf[ta * KW + (m >> 1)][m & 1], dq[ta & 1][m], dacc);
+            } else {
+                constexpr bool bias = ta == PT && m == PL + 1;
+                constexpr int tb = (ta == PT && m > PL) ? m - 1 : m;
+                if constexpr (bias) acc[TAPS] = mfma_bf16(ones, wq[st & 1][tb], acc[TAPS]);
+                else acc[ta * KW + tb] = mfma_bf16(af[ks & 1], wq[st & 1][tb], acc[ta * KW + tb]);
+            }
+            __builtin_amdgcn_sched_barrier(0);
+            if constexpr (!dstage) {
+                constexpr int wm = ks * (TAPS + 1) + ta * KW + (ta > PT ? 1 : 0) + m;     // weight-gradient MFMAs of the block so far
+                if constexpr (wm >= WM0) {
+                    constexpr int p0 = ((wm - WM0) * NPIECE) / (NWM - WM0), p1 = ((wm - WM0 + 1) * NPIECE) / (NWM - WM0);
+                    static_for<p0, p1>(piece);
+                    __builtin_amdgcn_sched_barrier(0);
+                }
+            }
+        };
+        static_for<0, NJ>([&](auto I_) { prep(std::integral_constant<int, NSTAGE>{}, I_); });
+#pragma unroll 1
+        for (int it = 0; it < 4; ++it) {
+            const int wr = 2 * wvs + (it >> 1), col0 = 32 * (it & 1);
+            const int itn = (it + 1) & 3;                                      // the last block prepares the first again: unused, in range
+            ug = ugb + wr * ROWB + col0 * 64;
+            ux = uxb + (wr * TW + col0) * 64;
+            ugn = ugb + (2 * wvs + (itn >> 1)) * ROWB + 32 * (itn & 1) * 64;
+            oh = h0 + wr;
+            ow = w0 + col0 + r;
+#pragma unroll
+            for (int i = 0; i < 16; ++i) dacc[i] = 0.f;
+            static_for<0, NSTAGE>([&](auto S_) {
+                constexpr int S = decltype(S_)::value;
+                constexpr int nm = S < KH ? NJ : KW + ((S - KH) % KH == PT ? 1 : 0);
+                static_for<0, nm>([&](auto M_) { step(S_, M_); });
+            });
         }
         if (has_next) stage_write(cur ^ 1);
         __syncthreads();
@@ -519,11 +589,14 @@ int launch_f(const mgx_conv_desc& d, const bf16_t* x, const bf16_t* g, const flo
     const int tiles_h = (d.hout + WTH - 1) / WTH, tiles_w = (d.wout + G::TW - 1) / G::TW;
     const long ntiles = (long)d.nimg * tiles_h * tiles_w;
     if (ntiles <= 0 || ntiles >= (1L << 31)) return MGX_ERR_ARG;
-    if (hipFuncSetAttribute((const void*)bbwd_kernel<KH, KW>, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS) !=
-        hipSuccess)
-        return MGX_ERR_LAUNCH;
-    hipLaunchKernelGGL((bbwd_kernel<KH, KW>), dim3(WGRID), dim3(256), G::LDS, st, d, x, g, w, dx, partial, ntiles, tiles_h,
-                       tiles_w, act_alpha);
+    const void* fn = act_alpha > 0.f ? (const void*)bbwd_kernel<KH, KW, true> : (const void*)bbwd_kernel<KH, KW, false>;
+    if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS) != hipSuccess) return MGX_ERR_LAUNCH;
+    if (act_alpha > 0.f)
+        hipLaunchKernelGGL((bbwd_kernel<KH, KW, true>), dim3(WGRID), dim3(256), G::LDS, st, d, x, g, w, dx, partial, ntiles,
+                           tiles_h, tiles_w, act_alpha);
+    else
+        hipLaunchKernelGGL((bbwd_kernel<KH, KW, false>), dim3(WGRID), dim3(256), G::LDS, st, d, x, g, w, dx, partial, ntiles,
+                           tiles_h, tiles_w, act_alpha);
     const long total = (long)G::TAPS * 1024 + (db ? d.ngemm : 0);
     hipLaunchKernelGGL(bwgrad_reduce_kernel, dim3((unsigned)((total + 63) / 64)), dim3(1024), 0, st, d, partial, dw, db,
                        WGRID, 1, G::TAPS);
