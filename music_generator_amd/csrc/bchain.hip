@@ -14,6 +14,10 @@
 // Input rows are requested one step ahead (global -> registers -> LDS ring).  Zero padding of every layer is
 // the reference's: ring rows outside the image and positions outside the image's columns hold zeros, not
 // values computed from padded input.
+// A strip may be cut into pieces of rows, one wave each, so that the workgroups of a launch fill the chip's 256
+// CUs evenly (a workgroup occupies a CU alone; 828 workgroups of equal length take as long as 1024).  A piece
+// starts one row above its first output row: the rows of the inner layers it computes before their own inputs
+// are complete feed only output rows above the piece, which it does not store.
 // LDS position layout, operand fragments, accumulation order (bias first, taps row-major, two 16-channel steps
 // a tap), activation and the lane exchange before the stores are those of bconv.hip: results are bit-identical
 // to the layer-by-layer launches of mgx_conv_gemm_bf16.
@@ -47,6 +51,7 @@ constexpr int chain_lds() { return chain_wave_lds<NL>() * WAVES + chain_shared_f
 
 struct ChainDesc {
     int nimg, h, w, strips;                // strips per image row
+    int nseg, seg_rows;                    // a strip is walked in nseg pieces of seg_rows output rows, one wave each
     float alpha[3];
 };
 
@@ -120,9 +125,13 @@ __global__ __launch_bounds__(64 * WAVES) void bchain_kernel(ChainDesc d, const b
         __syncthreads();
     }
     const long gw = (long)blockIdx.x * WAVES + wv;
-    if (gw >= (long)d.nimg * d.strips) return;       // no barrier anywhere below
-    const int img = (int)(gw / d.strips);
-    const int c0 = (int)(gw - (long)img * d.strips) * CW;
+    if (gw >= (long)d.nimg * d.strips * d.nseg) return;       // no barrier anywhere below
+    const int per_img = d.strips * d.nseg;
+    const int img = (int)(gw / per_img);
+    const int seg = (int)(gw - (long)img * per_img) / d.strips;
+    const int c0 = ((int)(gw - (long)img * per_img) - seg * d.strips) * CW;
+    const int r0 = seg * d.seg_rows, r1 = min(d.h, r0 + d.seg_rows);          // output rows of this wave
+    const int s_start = max(0, r0 - 1), s_end = min(d.h + NL - 2, r1 + NL - 2);
     const int o_in = c0 - PADS, o1 = o_in + 1, o2 = o1 + (K1 - 1) / 2;
 
     unsigned char* const my = lds + wv * chain_wave_lds<NL>();
@@ -274,20 +283,19 @@ __global__ __launch_bounds__(64 * WAVES) void bchain_kernel(ChainDesc d, const b
         __builtin_amdgcn_raw_buffer_store_b128(s1, ry, ocol + 32, 0, 0);
     };
 
-    // ---- prologue: rows -1 of the input and of layer 1 are zero padding; row 0 staged, rows 1 and 2 in flight ----
+    // ---- prologue: input rows s_start - 1 and s_start staged (a row outside the image loads as zeros), the next one
+    // in flight; layer-1 row s_start - 1 is zero padding in the first piece and feeds nothing that is stored in the others
     u32x4 svb[3];
-    row_load(0, svb);
-    {
-        const u32x4 zr[3] = {zero4, zero4, zero4};
-        row_write(i0, zr);
-    }
+    row_load(s_start - 1, svb);
+    row_write(i0, svb);
+    row_load(s_start, svb);
     ring_write(p1, zero4, zero4);
     row_write(i1, svb);
-    row_load(1, svb);
+    row_load(s_start + 1, svb);
     // from here: i0 = row s-1, i1 = row s, svb = row s+1 (in flight: requested one step ahead; with two waves on
     // a SIMD the other wave's step covers what is left of the latency)
 
-    for (int s = 0; s <= H + NL - 2; ++s) {
+    for (int s = s_start; s <= s_end; ++s) {
         row_write(i2, svb);
         row_load(s + 2, svb);
         // ---- layer 1, row s ----
@@ -301,7 +309,7 @@ __global__ __launch_bounds__(64 * WAVES) void bchain_kernel(ChainDesc d, const b
             ring_write(p2, zero4, zero4);
         }
         // ---- layer 2, row s-1 ----
-        if (s >= 1 && s - 1 < H) {
+        if (s > s_start && s - 1 < H) {
             f32x16 acc;
             acc_init(acc, bl + 32);
             const unsigned char* const rows[3] = {K1 == 3 ? p0 : p1, K1 == 3 ? p1 : p2, p2};
@@ -309,23 +317,23 @@ __global__ __launch_bounds__(64 * WAVES) void bchain_kernel(ChainDesc d, const b
             if constexpr (NL == 2) {
                 u32x4 s0, s1;
                 finish(acc, ia1, k11, s0, s1);
-                row_store(s - 1, s0, s1);
+                if (s - 1 >= r0) row_store(s - 1, s0, s1);
             } else {
                 finish_ring(acc, ia1, k11, q1, in2);
             }
-        } else if (NL == 3 && s >= 1) {
+        } else if (NL == 3 && s > s_start) {
             ring_write(q1, zero4, zero4);
         }
         // ---- layer 3 (2x2), row s-2 ----
         if constexpr (NL == 3) {
-            if (s >= 2) {
+            if (s >= s_start + 2) {
                 f32x16 acc;
                 acc_init(acc, bl + 64);
                 const unsigned char* const rows[3] = {q0, q1, q1};
                 conv_row(std::integral_constant<int, KLAST>{}, std::integral_constant<int, 0>{}, wf0, wl2, rows, acc);
                 u32x4 s0, s1;
                 finish(acc, ia2, k12, s0, s1);
-                row_store(s - 2, s0, s1);
+                if (s - 2 >= r0) row_store(s - 2, s0, s1);
             }
         }
         // rotate the rings
@@ -338,7 +346,7 @@ __global__ __launch_bounds__(64 * WAVES) void bchain_kernel(ChainDesc d, const b
 template <int NL, int KLAST, int WAVES>
 int launch_chain(const ChainDesc& d, const bf16_t* x, const float* const* w, const float* const* b, bf16_t* y,
                  hipStream_t st) {
-    const long waves = (long)d.nimg * d.strips;
+    const long waves = (long)d.nimg * d.strips * d.nseg;
     const long blocks = (waves + WAVES - 1) / WAVES;
     if (blocks <= 0 || blocks >= (1L << 31)) return MGX_ERR_ARG;
     constexpr int lds = chain_lds<NL, KLAST, WAVES>();
@@ -362,6 +370,25 @@ extern "C" int mgx_conv_chain_bf16_supported(int64_t nimg, int h, int w, int nla
     return 0;
 }
 
+// Pieces per strip: the count (1 .. 8, pieces of 16 rows or more) for which the launch's workgroups, one per CU at a
+// time on the 256 CUs of an MI355X, take the fewest row steps: rounds of workgroups x (rows of a piece + the rows a
+// piece computes in front of its first output row).
+static void chain_pieces(ChainDesc& d, int nlayers, int waves_per_group) {
+    long best = -1;
+    for (int n = 1; n <= 8; ++n) {
+        const int rows = (d.h + n - 1) / n;
+        if (n > 1 && rows < 16) break;
+        const int used = (d.h + rows - 1) / rows;            // pieces that hold any row
+        const long groups = ((long)d.nimg * d.strips * used + waves_per_group - 1) / waves_per_group;
+        const long cost = ((groups + 255) / 256) * (rows + nlayers + 1);
+        if (best < 0 || cost < best) {
+            best = cost;
+            d.nseg = used;
+            d.seg_rows = rows;
+        }
+    }
+}
+
 extern "C" int mgx_conv_chain_bf16(int64_t nimg, int h, int w, int nlayers, const int* ksizes, const void* x,
                                    const float* const* weights, const float* const* biases, const float* alphas,
                                    void* y, void* stream) {
@@ -379,12 +406,15 @@ extern "C" int mgx_conv_chain_bf16(int64_t nimg, int h, int w, int nlayers, cons
     bf16_t* yb = (bf16_t*)y;
     if (nlayers == 3) {
         d.strips = (w + chain_cw<3, 2>() - 1) / chain_cw<3, 2>();
+        chain_pieces(d, 3, 8);
         return launch_chain<3, 2, 8>(d, xb, weights, biases, yb, st);
     }
     if (ksizes[1] == 3) {
         d.strips = (w + chain_cw<2, 3>() - 1) / chain_cw<2, 3>();
+        chain_pieces(d, 2, 8);
         return launch_chain<2, 3, 8>(d, xb, weights, biases, yb, st);
     }
     d.strips = (w + chain_cw<2, 2>() - 1) / chain_cw<2, 2>();
+    chain_pieces(d, 2, 8);
     return launch_chain<2, 2, 8>(d, xb, weights, biases, yb, st);
 }

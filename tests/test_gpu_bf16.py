@@ -957,13 +957,15 @@ def test_bf16_discriminator_forward_with_and_without_pairs(bf16_precision):
 @pytest.mark.parametrize("h,w,n,ks", [(16, 64, 1, (3, 3, 2)), (8, 29, 2, (3, 3, 2)), (9, 30, 1, (3, 3, 2)),
                                       (20, 45, 2, (3, 3)), (32, 100, 3, (3, 2)), (48, 333, 1, (3, 3, 2)),
                                       (17, 31, 1, (3, 2)), (64, 500, 2, (3, 3)), (2, 8, 1, (3, 3, 2)),
-                                      (33, 61, 5, (3, 3, 2))])
+                                      (33, 61, 5, (3, 3, 2)), (50, 40, 1, (3, 3, 2)), (100, 64, 2, (3, 2)),
+                                      (130, 33, 1, (3, 3))])
 def test_bf16_conv_chain_equals_separate_launches(h, w, n, ks):
     """mgx_conv_chain_bf16 (two or three convolution + activation layers in one launch, a wave streaming a strip of
     columns down the rows with the inner layers' rows in LDS rings) against one launch of mgx_conv_gemm_bf16 per
     layer: the same MFMAs on the same bf16 values in the same order, so the outputs must be equal bit for bit,
     on ragged strips (widths that are not a multiple of 29 / 30 / 31), at the image borders (zero padding of
-    EVERY layer, rows and columns) and across images (more strips than one workgroup holds)."""
+    EVERY layer, rows and columns), across images (more strips than one workgroup holds) and where a strip is
+    walked in several pieces of rows (heights of 32 and more; pieces of unequal length at 33, 50, 100, 130)."""
     M.clear_session()
     layers = [L.Conv2D(32, (k, k), padding="same", kernel_initializer="he_normal") for k in ks]
     rng = np.random.default_rng(h * 100 + w + sum(ks))
