@@ -412,6 +412,13 @@ int mgx_conv_chain_bf16_supported(int64_t nimg, int h, int w, int nlayers, const
 int mgx_conv_chain_bf16(int64_t nimg, int h, int w, int nlayers, const int* ksizes, const void* x,
                         const float* const* weights, const float* const* biases, const float* alphas, void* y,
                         void* stream);
+/* The same launch for forward passes under tf.GradientTape (models.py:108-118, 133-144), whose backward reads
+ * every layer's output: ys[i] (bf16, shape of x) receives the output of layer i, the inner ones as the rows leave the
+ * activation on their way into the rings.  Bit-identical to nlayers calls of mgx_conv_gemm_bf16; the chain's input is
+ * read once and no inner output is read back. */
+int mgx_conv_chain_bf16_taped(int64_t nimg, int h, int w, int nlayers, const int* ksizes, const void* x,
+                              const float* const* weights, const float* const* biases, const float* alphas,
+                              void* const* ys, void* stream);
 
 /* From-audio 1x1 convolution (models.py:256): x float32 (npos, 2) -> y bf16 (npos, 128) with kernel w
  * (2,128) and bias (128) float32, optional tanh(v)+v/alpha epilogue (act_alpha > 0) and derivative

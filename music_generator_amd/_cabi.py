@@ -130,6 +130,7 @@ PROTOTYPES = {
     "mgx_audio_conv3_bf16": (_I, [_I64, _I, _I, _P, _P, _P, _F, _P, _P, _F, _P, _P]),
     "mgx_conv_chain_bf16_supported": (_I, [_I64, _I, _I, _I, _P]),
     "mgx_conv_chain_bf16": (_I, [_I64, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P]),
+    "mgx_conv_chain_bf16_taped": (_I, [_I64, _I, _I, _I, _P, _P, _P, _P, _P, _P, _P]),
     "mgx_conv_wgrad_bf16_workspace": (_I64, [_DESC]),
     "mgx_conv_wgrad_bf16": (_I, [_DESC, _P, _P, _P, _P, _P, _I64, _P]),
     "mgx_conv_bwd_bf16_supported": (_I, [_DESC]),

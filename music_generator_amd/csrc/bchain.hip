@@ -91,12 +91,16 @@ __device__ __forceinline__ void chain_weights(const float* __restrict__ w, int r
     }
 }
 
-template <int NL, int KLAST, int WAVES>
+// TAPE: the outputs of the inner layers are also written to t0 (layer 1) and t1 (layer 2 of three), for forward
+// passes whose backward reads every layer's output: each wave stores the columns and rows it owns (the halo
+// columns and the rows above a piece are the neighbours').
+template <int NL, int KLAST, int WAVES, bool TAPE>
 __global__ __launch_bounds__(64 * WAVES) void bchain_kernel(ChainDesc d, const bf16_t* __restrict__ x,
                                                            const float* __restrict__ w0, const float* __restrict__ b0,
                                                            const float* __restrict__ w1, const float* __restrict__ b1,
                                                            const float* __restrict__ w2, const float* __restrict__ b2,
-                                                           bf16_t* __restrict__ y) {
+                                                           bf16_t* __restrict__ y, bf16_t* __restrict__ t0,
+                                                           bf16_t* __restrict__ t1) {
     static_assert(NL == 2 || KLAST == 2, "three layers end in the 2x2 convolution");
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     constexpr int CW = chain_cw<NL, KLAST>();
@@ -201,8 +205,15 @@ __global__ __launch_bounds__(64 * WAVES) void bchain_kernel(ChainDesc d, const b
     // Inner layers: activation, then straight into the ring as four 8-byte pieces (channels 8g + 4h .. + 3 of the
     // lane's position are bytes [16g + 8h, 16g + 8h + 8) of its 64): no exchange between the lane halves.
     const int wg8 = cxoff(r, 0) + 8 * h, wsw = (r >> 2) & 3;
-    auto finish_ring = [&](f32x16& a, float ia, float k1, unsigned char* slot, bool inside) {
+    // tp / trow / tcol: where the row goes on the tape (TAPE only; tcol is out of range for lanes that own no column of it)
+    auto finish_ring = [&](f32x16& a, float ia, float k1, unsigned char* slot, bool inside, bf16_t* tp, int trow,
+                           unsigned tcol) {
         mfma_result_wait(a);
+        const bool taped = TAPE && trow >= r0 && trow < r1;
+        __amdgpu_buffer_rsrc_t rt = __builtin_amdgcn_make_buffer_rsrc((void*)x, 0, 0u, 0x00020000);
+        if (taped)
+            rt = __builtin_amdgcn_make_buffer_rsrc((void*)(tp + ((long)img * H + trow) * W * 32), 0, (unsigned)W * 64u,
+                                                   0x00020000);
 #pragma unroll
         for (int g = 0; g < 4; ++g) {
             float y0, y1, y2, y3, dd;
@@ -213,6 +224,8 @@ __global__ __launch_bounds__(64 * WAVES) void bchain_kernel(ChainDesc d, const b
             u32x2 o = {bf_pack(y0, y1), bf_pack(y2, y3)};
             if (!inside) o = (u32x2){0u, 0u};
             *(u32x2*)(slot + wg8 + ((g ^ wsw) << 4) - ((0 ^ wsw) << 4)) = o;
+            // channels 8g + 4h .. + 3 of the lane's position: bytes [16g + 8h, + 8) of its 64
+            if (taped) __builtin_amdgcn_raw_buffer_store_b64(o, rt, tcol + 16 * g, 0, 0);
         }
     };
     auto finish = [&](f32x16& a, float ia, float k1, u32x4& s0, u32x4& s1) {
@@ -275,6 +288,9 @@ __global__ __launch_bounds__(64 * WAVES) void bchain_kernel(ChainDesc d, const b
     const bool in1 = (unsigned)(o1 + r) < (unsigned)W;          // the lane's position of a layer-1 / layer-2 row
     const bool in2 = (unsigned)(o2 + r) < (unsigned)W;          // lies inside the image
     const unsigned ocol = (r < CW && c0 + r < W) ? (unsigned)((c0 + r) * 64 + 16 * h) : 0x80000000u;
+    // the lane's position of a layer-1 / layer-2 row is column o1 + r / o2 + r; the strip owns columns c0 .. c0 + CW - 1
+    const unsigned tcol1 = (o1 + r >= c0 && o1 + r < c0 + CW && o1 + r < W) ? (unsigned)((o1 + r) * 64 + 8 * h) : 0x80000000u;
+    const unsigned tcol2 = (o2 + r >= c0 && o2 + r < c0 + CW && o2 + r < W) ? (unsigned)((o2 + r) * 64 + 8 * h) : 0x80000000u;
     bf16_t* const yimg = y + (long)img * H * W * 32;
     auto row_store = [&](int row, u32x4 s0, u32x4 s1) {
         const __amdgpu_buffer_rsrc_t ry =
@@ -304,7 +320,7 @@ __global__ __launch_bounds__(64 * WAVES) void bchain_kernel(ChainDesc d, const b
             acc_init(acc, bl);
             const unsigned char* const rows[3] = {i0, i1, i2};
             conv_row(std::integral_constant<int, 3>{}, std::integral_constant<int, 18>{}, wf0, wl1, rows, acc);
-            finish_ring(acc, ia0, k10, p2, in1);
+            finish_ring(acc, ia0, k10, p2, in1, t0, s, tcol1);
         } else {
             ring_write(p2, zero4, zero4);
         }
@@ -319,7 +335,7 @@ __global__ __launch_bounds__(64 * WAVES) void bchain_kernel(ChainDesc d, const b
                 finish(acc, ia1, k11, s0, s1);
                 if (s - 1 >= r0) row_store(s - 1, s0, s1);
             } else {
-                finish_ring(acc, ia1, k11, q1, in2);
+                finish_ring(acc, ia1, k11, q1, in2, t1, s - 1, tcol2);
             }
         } else if (NL == 3 && s > s_start) {
             ring_write(q1, zero4, zero4);
@@ -343,19 +359,19 @@ __global__ __launch_bounds__(64 * WAVES) void bchain_kernel(ChainDesc d, const b
     }
 }
 
-template <int NL, int KLAST, int WAVES>
+template <int NL, int KLAST, int WAVES, bool TAPE>
 int launch_chain(const ChainDesc& d, const bf16_t* x, const float* const* w, const float* const* b, bf16_t* y,
-                 hipStream_t st) {
+                 bf16_t* t0, bf16_t* t1, hipStream_t st) {
     const long waves = (long)d.nimg * d.strips * d.nseg;
     const long blocks = (waves + WAVES - 1) / WAVES;
     if (blocks <= 0 || blocks >= (1L << 31)) return MGX_ERR_ARG;
     constexpr int lds = chain_lds<NL, KLAST, WAVES>();
     static_assert(lds <= 160 * 1024, "the chain kernel's LDS image exceeds a CU");
-    if (hipFuncSetAttribute((const void*)bchain_kernel<NL, KLAST, WAVES>, hipFuncAttributeMaxDynamicSharedMemorySize,
+    if (hipFuncSetAttribute((const void*)bchain_kernel<NL, KLAST, WAVES, TAPE>, hipFuncAttributeMaxDynamicSharedMemorySize,
                             lds) != hipSuccess)
         return MGX_ERR_LAUNCH;
-    hipLaunchKernelGGL((bchain_kernel<NL, KLAST, WAVES>), dim3((unsigned)blocks), dim3(64 * WAVES), lds, st, d, x, w[0],
-                       b[0], w[1], b[1], NL == 3 ? w[2] : nullptr, NL == 3 ? b[2] : nullptr, y);
+    hipLaunchKernelGGL((bchain_kernel<NL, KLAST, WAVES, TAPE>), dim3((unsigned)blocks), dim3(64 * WAVES), lds, st, d, x,
+                       w[0], b[0], w[1], b[1], NL == 3 ? w[2] : nullptr, NL == 3 ? b[2] : nullptr, y, t0, t1);
     return mgx_launch_status();
 }
 
@@ -389,32 +405,54 @@ static void chain_pieces(ChainDesc& d, int nlayers, int waves_per_group) {
     }
 }
 
-extern "C" int mgx_conv_chain_bf16(int64_t nimg, int h, int w, int nlayers, const int* ksizes, const void* x,
-                                   const float* const* weights, const float* const* biases, const float* alphas,
-                                   void* y, void* stream) {
-    if (!x || !y || !weights || !biases || !alphas || !mgx_conv_chain_bf16_supported(nimg, h, w, nlayers, ksizes))
+// ys[i] = output of layer i (bf16, shape of x); with `taped` every one is written, else only the last
+static int chain_run(int64_t nimg, int h, int w, int nlayers, const int* ksizes, const void* x,
+                     const float* const* weights, const float* const* biases, const float* alphas, void* const* ys,
+                     bool taped, void* stream) {
+    if (!x || !ys || !weights || !biases || !alphas || !mgx_conv_chain_bf16_supported(nimg, h, w, nlayers, ksizes))
         return MGX_ERR_ARG;
     ChainDesc d;
     d.nimg = (int)nimg; d.h = h; d.w = w;
     for (int i = 0; i < nlayers; ++i) {
-        if (!weights[i] || !biases[i] || !(alphas[i] > 0.f)) return MGX_ERR_ARG;
+        if (!weights[i] || !biases[i] || !(alphas[i] > 0.f) || ((taped || i == nlayers - 1) && !ys[i])) return MGX_ERR_ARG;
         d.alpha[i] = alphas[i];
     }
     if (nlayers == 2) d.alpha[2] = 1.f;
     hipStream_t st = (hipStream_t)stream;
     const bf16_t* xb = (const bf16_t*)x;
-    bf16_t* yb = (bf16_t*)y;
+    bf16_t* yb = (bf16_t*)ys[nlayers - 1];
+    bf16_t* t0 = taped ? (bf16_t*)ys[0] : nullptr;
+    bf16_t* t1 = (taped && nlayers == 3) ? (bf16_t*)ys[1] : nullptr;
     if (nlayers == 3) {
         d.strips = (w + chain_cw<3, 2>() - 1) / chain_cw<3, 2>();
         chain_pieces(d, 3, 8);
-        return launch_chain<3, 2, 8>(d, xb, weights, biases, yb, st);
+        return taped ? launch_chain<3, 2, 8, true>(d, xb, weights, biases, yb, t0, t1, st)
+                     : launch_chain<3, 2, 8, false>(d, xb, weights, biases, yb, t0, t1, st);
     }
     if (ksizes[1] == 3) {
         d.strips = (w + chain_cw<2, 3>() - 1) / chain_cw<2, 3>();
         chain_pieces(d, 2, 8);
-        return launch_chain<2, 3, 8>(d, xb, weights, biases, yb, st);
+        return taped ? launch_chain<2, 3, 8, true>(d, xb, weights, biases, yb, t0, t1, st)
+                     : launch_chain<2, 3, 8, false>(d, xb, weights, biases, yb, t0, t1, st);
     }
     d.strips = (w + chain_cw<2, 2>() - 1) / chain_cw<2, 2>();
     chain_pieces(d, 2, 8);
-    return launch_chain<2, 2, 8>(d, xb, weights, biases, yb, st);
+    return taped ? launch_chain<2, 2, 8, true>(d, xb, weights, biases, yb, t0, t1, st)
+                 : launch_chain<2, 2, 8, false>(d, xb, weights, biases, yb, t0, t1, st);
+}
+
+extern "C" int mgx_conv_chain_bf16(int64_t nimg, int h, int w, int nlayers, const int* ksizes, const void* x,
+                                   const float* const* weights, const float* const* biases, const float* alphas,
+                                   void* y, void* stream) {
+    if (nlayers < 2 || nlayers > 3) return MGX_ERR_ARG;
+    void* ys[3] = {nullptr, nullptr, nullptr};
+    ys[nlayers - 1] = y;
+    return chain_run(nimg, h, w, nlayers, ksizes, x, weights, biases, alphas, ys, false, stream);
+}
+
+extern "C" int mgx_conv_chain_bf16_taped(int64_t nimg, int h, int w, int nlayers, const int* ksizes, const void* x,
+                                         const float* const* weights, const float* const* biases, const float* alphas,
+                                         void* const* ys, void* stream) {
+    if (nlayers < 2 || nlayers > 3) return MGX_ERR_ARG;
+    return chain_run(nimg, h, w, nlayers, ksizes, x, weights, biases, alphas, ys, true, stream);
 }

@@ -389,6 +389,10 @@ class Model:
     # covers the other launch-saving rules of tape-free passes: the from-audio + 3x3 kernel (bf16) and the fade-in
     # blend in the epilogue of a block's last 1x1 convolution (float32 and bf16).
     use_conv_chains = os.environ.get("MGX_CONV_CHAINS", "1") != "0"      # MGX_CONV_CHAINS=0: layer by layer (measurements)
+    # True: the same groups of a TAPED bf16 pass run as one launch too (mgx_conv_chain_bf16_taped): every layer's
+    # output is written for the backward, but the inner ones are not read back (256 instead of 384 bytes a position
+    # and three-layer group); bit-identical tape.
+    use_taped_chains = os.environ.get("MGX_TAPED_CHAINS", "1") != "0"
 
     def _conv_chain(self, plan, i, n_consumers, x):
         """The longest run of plan steps starting at i that mgx_conv_chain_bf16 serves as one launch, or None."""
@@ -463,13 +467,20 @@ class Model:
                                     vals.pop(id(t), None)
                         skip = i + 1
                         continue
-            if (not save and Model.use_conv_chains and not isinstance(op, _FusedOp) and op.act_node is not None
-                    and K.bf16_enabled() and xs[0].dtype == torch.bfloat16):
+            if (Model.use_conv_chains and not isinstance(op, _FusedOp) and op.act_node is not None
+                    and K.bf16_enabled() and xs[0].dtype == torch.bfloat16
+                    and (not save or (Model.use_taped_chains and not K.BF16_SAVE_DERIVATIVE))):
                 chain = self._conv_chain(plan, i, n_consumers, xs[0])
                 if chain is not None:
-                    from .layers import conv_chain_forward
-                    vals[id(chain[-1].output)] = conv_chain_forward(
-                        [o.node.layer for o in chain], [o.act_node.layer.alpha_value for o in chain], xs[0])
+                    from .layers import conv_chain_forward, conv_chain_forward_taped
+                    chain_layers = [o.node.layer for o in chain]
+                    chain_alphas = [o.act_node.layer.alpha_value for o in chain]
+                    if save:
+                        # one launch that also writes the inner outputs; the tape gets every layer's entry
+                        vals[id(chain[-1].output)], entries = conv_chain_forward_taped(chain_layers, chain_alphas, xs[0])
+                        tape.extend(entries)
+                    else:
+                        vals[id(chain[-1].output)] = conv_chain_forward(chain_layers, chain_alphas, xs[0])
                     for t in op.inputs:
                         if last_use.get(id(t)) == i and t is not self.output:
                             vals.pop(id(t), None)

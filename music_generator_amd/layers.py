@@ -288,6 +288,16 @@ def conv_chain_forward(layers, alphas, x):
     return y
 
 
+def conv_chain_forward_taped(layers, alphas, x):
+    """The chain as one launch that also writes the inner layers' outputs: returns the last output and the tape
+    entries the layers' own forward calls would have produced (input, stored output, alpha of each)."""
+    ys = [K.empty(tuple(x.shape), dtype=torch.bfloat16) for _ in layers]
+    ops.conv_chain_bf16(x, [l.kernel.value() for l in layers], [l.bias.value() for l in layers], alphas,
+                        [l.kernel_size[0] for l in layers], ys)
+    saved = [_BSaved("conv", xin, None, yout, a) for xin, yout, a in zip([x] + ys[:-1], ys, alphas)]
+    return ys[-1], saved
+
+
 class _CastSaved(tuple):
     """(x, dact) of a float32 contraction whose input arrived as bf16 and was cast: the data-gradient goes
     back as bf16."""

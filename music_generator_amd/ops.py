@@ -710,10 +710,15 @@ def conv_chain_bf16_supported(n, h, w, ksizes) -> bool:
 
 def conv_chain_bf16(x, weights, biases, alphas, ksizes, y):
     """mgx_conv_chain_bf16: two or three Conv2D(32, k x k, same) + SoftRectifier layers on a bf16 (n, h, w, 32)
-    tensor in one launch, no tape."""
+    tensor in one launch.  y is the last layer's output, or a list with one tensor per layer (mgx_conv_chain_bf16_taped:
+    every layer's output is written, for forward passes that keep a tape)."""
     n, h, w, c = x.shape
     nl = len(ksizes)
-    if c != 32 or tuple(y.shape) != (n, h, w, 32) or x.dtype != torch.bfloat16 or y.dtype != torch.bfloat16:
+    taped = isinstance(y, (list, tuple))
+    outs = list(y) if taped else [y]
+    if taped and len(outs) != nl:
+        raise MgxError("conv_chain_bf16: one output tensor per layer")
+    if c != 32 or x.dtype != torch.bfloat16 or any(tuple(t.shape) != (n, h, w, 32) or t.dtype != torch.bfloat16 for t in outs):
         raise MgxError("conv_chain_bf16: x and y must be bf16 (n, h, w, 32) tensors of one shape")
     if not (len(weights) == len(biases) == len(alphas) == nl):
         raise MgxError("conv_chain_bf16: one kernel, bias and alpha per layer")
@@ -725,12 +730,17 @@ def conv_chain_bf16(x, weights, biases, alphas, ksizes, y):
     bp = (C.c_void_p * nl)(*[_p(t) for t in biases])
     al = (C.c_float * nl)(*[float(a) for a in alphas])
     e0 = PROFILER.start() if PROFILER is not None else None
-    check(_lib().mgx_conv_chain_bf16(n, h, w, nl, ks, _pb(x), wp, bp, al, _pb(y), K.stream_ptr()),
-          "mgx_conv_chain_bf16")
+    if taped:
+        yp = (C.c_void_p * nl)(*[_pb(t) for t in outs])
+        check(_lib().mgx_conv_chain_bf16_taped(n, h, w, nl, ks, _pb(x), wp, bp, al, yp, K.stream_ptr()),
+              "mgx_conv_chain_bf16_taped")
+    else:
+        check(_lib().mgx_conv_chain_bf16(n, h, w, nl, ks, _pb(x), wp, bp, al, _pb(y), K.stream_ptr()),
+              "mgx_conv_chain_bf16")
     if e0 is not None:
         px = n * h * w
-        PROFILER.stop("bchain_kernel<%s>" % ",".join(str(int(k)) for k in ksizes),
-                      2.0 * sum(k * k for k in ksizes) * 1024 * px, e0, px * 128)
+        PROFILER.stop("bchain_kernel<%s%s>" % (",".join(str(int(k)) for k in ksizes), ",taped" if taped else ""),
+                      2.0 * sum(k * k for k in ksizes) * 1024 * px, e0, px * 64 * (1 + (nl if taped else 1)))
 
 
 def conv_wgrad_bf16(d: ConvDesc, x, g, dw, dbias):

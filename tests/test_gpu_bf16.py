@@ -974,11 +974,12 @@ def test_bf16_conv_chain_equals_separate_launches(h, w, n, ks):
         layer.bias.assign(rng.uniform(-0.3, 0.3, (32,)).astype(np.float32))
     x = _dev_b(rng.uniform(-1, 1, (n, h, w, 32)))
     alphas = [7.0, 80000.0, 11000.0][:len(ks)]
-    cur = x
+    cur, inner = x, []
     for layer, alpha in zip(layers, alphas):
         nxt = torch.empty((n, h, w, 32), dtype=torch.bfloat16, device="cuda")
         ops.conv_gemm_bf16(layer._desc("f", n, h, w), cur, layer.kernel.value(), layer.bias.value(), nxt, act_alpha=alpha)
         cur = nxt
+        inner.append(nxt)
     want = cur
     assert ops.conv_chain_bf16_supported(n, h, w, ks)
     got = torch.full_like(want, float("nan"))
@@ -988,6 +989,13 @@ def test_bf16_conv_chain_equals_separate_launches(h, w, n, ks):
     diff = (got.float() - want.float()).abs()
     where = np.unravel_index(int(diff.argmax()), tuple(diff.shape))
     assert torch.equal(got.view(torch.int16), want.view(torch.int16)), "max abs difference %.3e at %s" % (float(diff.max()), where)
+    # the taped launch: every layer's output, each position written by the one wave that owns it
+    outs = [torch.full_like(want, float("nan")) for _ in ks]
+    ops.conv_chain_bf16(x, [l.kernel.value() for l in layers], [l.bias.value() for l in layers], alphas, ks, outs)
+    torch.cuda.synchronize()
+    for i, (o, ref) in enumerate(zip(outs, inner)):
+        assert bool(torch.isfinite(o.float()).all()), "layer %d: positions left unwritten" % i
+        assert torch.equal(o.view(torch.int16), ref.view(torch.int16)), "layer %d: %.3e" % (i, float((o.float() - ref.float()).abs().max()))
 
 
 def test_bf16_conv_chain_rejects_what_it_does_not_serve():
@@ -1007,8 +1015,10 @@ def test_bf16_conv_chain_rejects_what_it_does_not_serve():
 def test_bf16_discriminator_forward_with_and_without_chains(bf16_precision):
     """A tape-free discriminator forward (the metric passes of the step) through the chain kernel
     (Model.use_conv_chains, the default) against the same forward layer by layer: bit-identical logits, three chains
-    per grown block that is tall enough; with a tape the chain kernel is not used."""
+    per grown block that is tall enough.  With a tape the same groups run through the taped launch
+    (Model.use_taped_chains): the tape holds the tensors the layer-by-layer forward leaves on it, bit for bit."""
     from music_generator_amd.graph import Model
+    from music_generator_amd.layers import _BSaved
     d, g, comp, W = _build(4)
     model = d[3][1]
     for layer in model.layers:
@@ -1020,7 +1030,7 @@ def test_bf16_discriminator_forward_with_and_without_chains(bf16_precision):
     orig, orig_blend = ops.conv_chain_bf16, ops.conv1x1_blend_bf16
     ops.conv_chain_bf16 = lambda *a, **k: (calls.append(tuple(a[4])), orig(*a, **k))[1]
     ops.conv1x1_blend_bf16 = lambda *a, **k: (blends.append(1), orig_blend(*a, **k))[1]
-    chains = Model.use_conv_chains
+    chains, taped_chains = Model.use_conv_chains, Model.use_taped_chains
     try:
         Model.use_conv_chains = True
         y1 = model(x).clone()
@@ -1029,10 +1039,25 @@ def test_bf16_discriminator_forward_with_and_without_chains(bf16_precision):
         y0 = model(x).clone()
         assert len(calls) == n_chains
         Model.use_conv_chains = True
-        model.forward(x, save=True)
-        assert len(calls) == n_chains
+        Model.use_taped_chains = True
+        yt, tape_t = model.forward(x, save=True)
+        assert len(calls) == 2 * n_chains and calls[n_chains:] == calls[:n_chains]
+        Model.use_taped_chains = False
+        yl, tape_l = model.forward(x, save=True)
+        assert len(calls) == 2 * n_chains
+        assert torch.equal(yt, yl) and len(tape_t) == len(tape_l)
+        n_entries = 0
+        for a, b in zip(tape_t, tape_l):
+            assert type(a) is type(b)
+            if isinstance(a, _BSaved):
+                n_entries += 1
+                assert a.mode == b.mode and a.alpha == b.alpha and a.dact is None and b.dact is None
+                assert torch.equal(a.x, b.x) and (a.yact is None) == (b.yact is None)
+                assert a.yact is None or torch.equal(a.yact, b.yact)
+        assert n_entries >= 14, n_entries
     finally:
         Model.use_conv_chains = chains
+        Model.use_taped_chains = taped_chains
         ops.conv_chain_bf16 = orig
         ops.conv1x1_blend_bf16 = orig_blend
     assert n_chains >= 6 and set(calls) == {(3, 2), (3, 3, 2), (3, 3)}, calls
