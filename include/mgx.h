@@ -367,6 +367,15 @@ int mgx_conv_gemm_bf16(const mgx_conv_desc* d, const void* x, const float* w, co
  * descriptor.  Rounded where the two launches it replaces round (results are bit-identical to them). */
 int mgx_conv1x1_blend_bf16(const mgx_conv_desc* d, const void* x, const float* w, const float* bias, const void* old,
                            const float* alpha, void* y, void* stream);
+/* The same launch with `old` given as the layer that produces it in the fade-in graph (models.py:292-296): the old
+ * stage's from-audio Conv2D(128, 1x1) + SoftRectifier(audio_alpha) applied to the average-pooled 2-channel audio
+ * (float32, (nimg, h, w, 2) of the output's height and width), kernel audio_w (2, 128) and bias audio_b (128).  Every
+ * element of `old` is re-computed in the epilogue with the arithmetic of mgx_pointwise2_bf16_fwd and rounded to bf16
+ * as that kernel stores it (8 bytes a position read instead of 256, and no launch that writes them): results are
+ * bit-identical to mgx_pointwise2_bf16_fwd + mgx_conv_gemm_bf16 + mgx_weighted_sum_bf16_fwd.  128 output channels. */
+int mgx_conv1x1_blend_audio_bf16(const mgx_conv_desc* d, const void* x, const float* w, const float* bias,
+                                 const float* audio, const float* audio_w, const float* audio_b, float audio_alpha,
+                                 const float* alpha, void* y, void* stream);
 /* The same for float32 tensors (the 1x1 tile kernel, 32 -> 128 channels): mgx_conv1x1_blend_supported tells whether
  * the descriptor is served. */
 int mgx_conv1x1_blend_supported(const mgx_conv_desc* d);

@@ -23,7 +23,8 @@
 // out of an activation: dY (.) f'), either the stored derivative itself or the activation's stored output, from
 // which the derivative is recovered; plain; or (1x1 kernels, passes that keep no tape) bias + activation followed by
 // the fade-in blend (1 - alpha) old + alpha y of trainer/models.py:30-35 with a bf16 tensor `old` of the output's
-// shape, in place of a WeightedSum launch that would read the activation back.
+// shape, in place of a WeightedSum launch that would read the activation back; the same with `old` itself re-computed
+// per element from the 2-channel audio it is a 1x1 convolution + activation of (8 bytes a position read instead of 256).
 #include <cstdlib>
 #include "bf16.h"
 #include "../../include/mgx.h"
@@ -39,16 +40,26 @@ constexpr int npix() { return (TH + KH - 1) * (NT * 32 + KW - 1); }
 // byte offset of quad q (8 channels) of tile position p
 __device__ __forceinline__ int xoff(int p, int q) { return p * 64 + ((q ^ ((p >> 2) & 3)) << 4); }
 
+// The other input of the blend as the layer that produces it: Conv2D(128, 1x1) + SoftRectifier(alpha) on float32
+// audio of the output's height and width (trainer/models.py:292-296), kernel (2, 128) and bias (128) float32.
+struct BlendAudio {
+    const float* audio;
+    const float* w;
+    const float* b;
+    float inv_alpha;
+};
+
 template <int KH, int KW, int EPI, int TH, int NT>
 __global__ __launch_bounds__(64 * TH) void bconv_kernel(mgx_conv_desc d, const bf16_t* __restrict__ x,
                                                        const float* __restrict__ w, const float* __restrict__ bias,
                                                        bf16_t* __restrict__ y, bf16_t* __restrict__ dact,
                                                        const bf16_t* __restrict__ ymul, long ntiles, int tiles_h,
                                                        int tiles_w, int gin_w, int scat,
-                                                       const float* __restrict__ blend_alpha) {
+                                                       const float* __restrict__ blend_alpha, BlendAudio ba) {
     // EPI: 0 plain, 1 bias + activation (+ derivative), 2 multiply by ymul, 3 = 1 followed by the blend with ymul,
-    // 4 multiply by the activation derivative recovered from ymul = the activation's stored OUTPUT (dact_from_y)
-    constexpr bool ACT = EPI == 1 || EPI == 3, PRE = EPI == 2 || EPI == 3 || EPI == 4;
+    // 4 multiply by the activation derivative recovered from ymul = the activation's stored OUTPUT (dact_from_y),
+    // 5 = 3 with the blend's other input re-computed from the audio (ba) instead of read from ymul
+    constexpr bool ACT = EPI == 1 || EPI == 3 || EPI == 5, PRE = EPI == 2 || EPI == 3 || EPI == 4;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     constexpr int TW = NT * 32, NTHR = 64 * TH;
     constexpr int IH = TH + KH - 1, IW = TW + KW - 1, TAPS = KH * KW, NPIX = IH * IW;
@@ -136,6 +147,10 @@ __global__ __launch_bounds__(64 * TH) void bconv_kernel(mgx_conv_desc d, const b
     float* bl = (float*)(xt + 2 * NPIX * 64);
     if (ACT)
         for (int i = tid; i < N; i += NTHR) bl[i] = d.nbias > 0 ? bias[i] : 0.f;
+    // the from-audio layer of the blend's other input: {w[0][c], w[1][c], bias[c], -} per output channel c
+    f32x4* fa = (f32x4*)(bl + N);
+    if (EPI == 5)
+        for (int i = tid; i < 128; i += NTHR) fa[i] = (f32x4){ba.w[i], ba.w[128 + i], ba.b[i], 0.f};
 
     long t = blockIdx.x;
     int oc = 0;
@@ -166,6 +181,7 @@ __global__ __launch_bounds__(64 * TH) void bconv_kernel(mgx_conv_desc d, const b
     // what the epilogue of this step needs from global memory (the lane's 2 x 32 bytes of `ymul`) is requested
     // before the MFMA phase, so that its latency is covered by it
     u32x4 pre_m[NT][2];
+    f32x2 pre_a[NT];
     auto epilogue_addr = [&](long t_, int nc_, long& rowoff, unsigned& row_bytes, int& pstride, int& coff, int& w0) {
         long img; int h0;
         tile_of(t_, img, h0, w0);
@@ -176,6 +192,16 @@ __global__ __launch_bounds__(64 * TH) void bconv_kernel(mgx_conv_desc d, const b
         coff = scat ? (nc_ & 1) * 64 + 16 * h : nc_ * 64 + 16 * h;    // the lane's first 16 bytes; the second 32 further
     };
     auto epilogue_prefetch = [&](long t_, int nc_) {
+        if (EPI == 5) {
+            long img; int h0, w0;
+            tile_of(t_, img, h0, w0);
+            const int row = h0 + wvs;
+            const __amdgpu_buffer_rsrc_t ra = __builtin_amdgcn_make_buffer_rsrc(
+                (void*)(ba.audio + ((img * H + row) * (long)W) * 2), 0, row < H ? (unsigned)W * 8u : 0u, 0x00020000);
+#pragma unroll
+            for (int nt = 0; nt < NT; ++nt)
+                pre_a[nt] = __builtin_bit_cast(f32x2, __builtin_amdgcn_raw_buffer_load_b64(ra, (unsigned)((w0 + nt * 32 + r) * 8), 0, 0));
+        }
         if (PRE) {
             long rowoff; unsigned row_bytes; int pstride, coff, w0;
             epilogue_addr(t_, nc_, rowoff, row_bytes, pstride, coff, w0);
@@ -215,9 +241,33 @@ __global__ __launch_bounds__(64 * TH) void bconv_kernel(mgx_conv_desc d, const b
 #pragma unroll
                     for (int i = 0; i < 16; i += 2) o[i >> 1] = bf_pack(a[i], a[i + 1]);
                 }
-                if (EPI == 3) {
+                if (EPI == 3 || EPI == 5) {
                     const float al = blend_alpha[0], om = 1.0f - al;
-                    const u32x4 m0 = pre_m[nt][0], m1 = pre_m[nt][1];
+                    u32x4 m0, m1;
+                    if (EPI == 5) {
+                        // the stand-alone from-audio kernel's arithmetic (two fused multiply-adds from the bias,
+                        // activation, rounding to bf16) for the lane's channels 8h .. 8h+7 and 16+8h .. 16+8h+7 of chunk nc_
+                        const float a0 = pre_a[nt][0], a1 = pre_a[nt][1], fk1 = 1.0f + ba.inv_alpha;
+#pragma unroll
+                        for (int half = 0; half < 2; ++half) {
+                            unsigned m[4];
+#pragma unroll
+                            for (int i = 0; i < 8; i += 2) {
+                                const f32x4 c0 = fa[nc_ * 32 + 16 * half + 8 * h + i], c1 = fa[nc_ * 32 + 16 * half + 8 * h + i + 1];
+                                float v0 = __builtin_fmaf(a1, c0[1], __builtin_fmaf(a0, c0[0], c0[2]));
+                                float v1 = __builtin_fmaf(a1, c1[1], __builtin_fmaf(a0, c1[0], c1[2]));
+                                float dv;
+                                act_bf16(v0, ba.inv_alpha, fk1, v0, dv);
+                                act_bf16(v1, ba.inv_alpha, fk1, v1, dv);
+                                m[i >> 1] = bf_pack(v0, v1);
+                            }
+                            if (half == 0) m0 = (u32x4){m[0], m[1], m[2], m[3]};
+                            else m1 = (u32x4){m[0], m[1], m[2], m[3]};
+                        }
+                    } else {
+                        m0 = pre_m[nt][0];
+                        m1 = pre_m[nt][1];
+                    }
 #pragma unroll
                     for (int i = 0; i < 4; ++i) {
                         o[i] = bf_pack(mgx_blend(om, bf_lo(m0[i]), al, bf_lo(o[i])), mgx_blend(om, bf_hi(m0[i]), al, bf_hi(o[i])));
@@ -266,7 +316,7 @@ __global__ __launch_bounds__(64 * TH) void bconv_kernel(mgx_conv_desc d, const b
         const bool need_x = has_next && (kchunks > 1 || ocn == 0);
         if (need_x) stage_load(tn, kchunks > 1 ? ocn : 0);
         const bool ep_now = kchunks == 1 || oc == S - 1;
-        if (ep_now && PRE) epilogue_prefetch(t, nchunks > 1 ? oc : 0);
+        if (ep_now && (PRE || EPI == 5)) epilogue_prefetch(t, nchunks > 1 ? oc : 0);
         const unsigned char* xb = xt + cur * (NPIX * 64);
         const int kc = kchunks > 1 ? oc : 0, nc = nchunks > 1 ? oc : 0;
         const unsigned char* wb = wl + ((nc * TAPS * (K >> 4) + kc * 2) * 64 + lane) * 16;
@@ -296,15 +346,17 @@ __global__ __launch_bounds__(64 * TH) void bconv_kernel(mgx_conv_desc d, const b
 
 template <int KH, int KW, int TH, int NT>
 int launch_shape(const mgx_conv_desc& d, const bf16_t* x, const float* w, const float* bias, bf16_t* y, bf16_t* dact,
-                 const bf16_t* ymul, hipStream_t st, int gin_w, int scat, const float* blend_alpha = nullptr) {
+                 const bf16_t* ymul, hipStream_t st, int gin_w, int scat, const float* blend_alpha = nullptr,
+                 const BlendAudio* audio = nullptr) {
     constexpr int TW = NT * 32;
     const int tiles_h = (d.hin + TH - 1) / TH, tiles_w = (d.win + TW - 1) / TW;
     const long ntiles = (long)d.nimg * tiles_h * tiles_w;
     if (ntiles <= 0 || ntiles >= (1L << 31)) return MGX_ERR_ARG;
     const unsigned grid = (unsigned)(ntiles < 256 ? ntiles : 256);
-    const int lds = KH * KW * d.cin * d.ngemm * 2 + 2 * npix<KH, KW, TH, NT>() * 64 + d.ngemm * 4;
+    const int lds = KH * KW * d.cin * d.ngemm * 2 + 2 * npix<KH, KW, TH, NT>() * 64 + d.ngemm * 4 + (audio ? 128 * 16 : 0);
     if (lds > 160 * 1024) return MGX_ERR_ARG;
-    const int epi = blend_alpha != nullptr ? 3
+    const BlendAudio ba = audio ? *audio : BlendAudio{nullptr, nullptr, nullptr, 0.f};
+    const int epi = blend_alpha != nullptr ? (audio ? 5 : 3)
                     : (ymul != nullptr ? (d.act_alpha > 0.f ? 4 : 2) : ((d.nbias > 0 || d.act_alpha > 0.f) ? 1 : 0));
 #define MGX_B(E)                                                                                                     \
     do {                                                                                                             \
@@ -312,10 +364,13 @@ int launch_shape(const mgx_conv_desc& d, const bf16_t* x, const float* w, const 
                                 hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)                      \
             return MGX_ERR_LAUNCH;                                                                                   \
         hipLaunchKernelGGL((bconv_kernel<KH, KW, E, TH, NT>), dim3(grid), dim3(64 * TH), lds, st, d, x, w, bias, y,  \
-                           dact, ymul, ntiles, tiles_h, tiles_w, gin_w, scat, blend_alpha);                          \
+                           dact, ymul, ntiles, tiles_h, tiles_w, gin_w, scat, blend_alpha, ba);                      \
     } while (0)
     if (epi == 3) {
         if constexpr (KH == 1 && KW == 1) MGX_B(3);
+        else return MGX_ERR_ARG;
+    } else if (epi == 5) {
+        if constexpr (KH == 1 && KW == 1) MGX_B(5);
         else return MGX_ERR_ARG;
     } else if (epi == 4) MGX_B(4);
     else if (epi == 2) MGX_B(2);
@@ -329,12 +384,13 @@ int launch_shape(const mgx_conv_desc& d, const bf16_t* x, const float* w, const 
 // weights; 8 x 64 tiles otherwise.  MGX_BCONV_TILE=8 / 16 forces a shape (measurements).
 template <int KH, int KW>
 int launch_b(const mgx_conv_desc& d, const bf16_t* x, const float* w, const float* bias, bf16_t* y, bf16_t* dact,
-             const bf16_t* ymul, hipStream_t st, int gin_w, int scat, const float* blend_alpha = nullptr) {
+             const bf16_t* ymul, hipStream_t st, int gin_w, int scat, const float* blend_alpha = nullptr,
+             const BlendAudio* audio = nullptr) {
     const int lds16 = KH * KW * d.cin * d.ngemm * 2 + 2 * npix<KH, KW, 16, 1>() * 64 + d.ngemm * 4;
     bool tall = d.hin >= 16 && d.hin % 16 == 0 && lds16 <= 160 * 1024;
     if (const char* e = getenv("MGX_BCONV_TILE")) tall = e[0] == '1' && lds16 <= 160 * 1024;
-    if (tall) return launch_shape<KH, KW, 16, 1>(d, x, w, bias, y, dact, ymul, st, gin_w, scat, blend_alpha);
-    return launch_shape<KH, KW, 8, 2>(d, x, w, bias, y, dact, ymul, st, gin_w, scat, blend_alpha);
+    if (tall) return launch_shape<KH, KW, 16, 1>(d, x, w, bias, y, dact, ymul, st, gin_w, scat, blend_alpha, audio);
+    return launch_shape<KH, KW, 8, 2>(d, x, w, bias, y, dact, ymul, st, gin_w, scat, blend_alpha, audio);
 }
 
 }  // namespace
@@ -391,4 +447,19 @@ extern "C" int mgx_conv1x1_blend_bf16(const mgx_conv_desc* dp, const void* x, co
     if (dp->nbias > 0 && (!bias || dp->nbias != dp->ngemm)) return MGX_ERR_ARG;
     return launch_b<1, 1>(*dp, (const bf16_t*)x, w, bias, (bf16_t*)y, nullptr, (const bf16_t*)old, (hipStream_t)stream, 0, 0,
                           alpha);
+}
+
+// The same launch with `old` given as the layer that produces it in the fade-in graph (models.py:292-296): the
+// Conv2D(128, 1x1) + SoftRectifier(audio_alpha) on the pooled 2-channel float32 audio (nimg, h, w, 2), kernel
+// audio_w (2, 128), bias audio_b (128).  Each element of `old` is re-computed in the epilogue with the arithmetic of
+// mgx_pointwise2_bf16_fwd and rounded to bf16 as that kernel stores it: bit-identical to the three launches.
+extern "C" int mgx_conv1x1_blend_audio_bf16(const mgx_conv_desc* dp, const void* x, const float* w, const float* bias,
+                                            const float* audio, const float* audio_w, const float* audio_b,
+                                            float audio_alpha, const float* alpha, void* y, void* stream) {
+    if (!dp || !x || !w || !audio || !audio_w || !audio_b || !alpha || !y || !mgx_conv_bf16_supported(dp)) return MGX_ERR_ARG;
+    if (dp->kh != 1 || dp->kw != 1 || dp->sh != 1 || dp->dkh != 1 || dp->accumulate || dp->ngemm != 128) return MGX_ERR_ARG;
+    if (dp->nbias > 0 && (!bias || dp->nbias != dp->ngemm)) return MGX_ERR_ARG;
+    if (!(audio_alpha > 0.f)) return MGX_ERR_ARG;
+    const BlendAudio ba = {audio, audio_w, audio_b, 1.0f / audio_alpha};
+    return launch_b<1, 1>(*dp, (const bf16_t*)x, w, bias, (bf16_t*)y, nullptr, nullptr, (hipStream_t)stream, 0, 0, alpha, &ba);
 }

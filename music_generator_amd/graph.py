@@ -426,10 +426,36 @@ class Model:
             tape.plan = plan
         producer, n_consumers = self._plan_links(plan)
         skip = -1
+        # outputs of from-audio layers not computed yet (tape-free bf16 passes): id -> (layer, alpha, audio).  The
+        # fade-in blend re-computes such an input in its epilogue; any other reader gets it computed on first use.
+        deferred: Dict[int, tuple] = {}
+
+        def value_of(t):
+            pending = deferred.pop(id(t), None)
+            if pending is not None:
+                vals[id(t)] = pending[0].forward([pending[2]], False, act_alpha=pending[1])[0]
+            return vals[id(t)]
+
         for i, op in enumerate(plan):
             if i <= skip:
                 continue
-            xs = [vals[id(t)] for t in op.inputs]
+            xs = [value_of(t) for t in op.inputs]
+            if (not save and Model.use_conv_chains and not isinstance(op, _FusedOp) and op.act_node is not None
+                    and K.bf16_enabled() and xs[0].dtype == torch.float32 and op.output is not self.output
+                    and n_consumers.get(id(op.output), 0) == 1):
+                # the old stage's from-audio convolution on the pooled audio, read only by the fade-in WeightedSum
+                # as its first input: left to the blend's epilogue (mgx_conv1x1_blend_audio_bf16)
+                from .layers import blend_audio_source
+                reader = next((o for o in plan[i + 1:] if any(t is op.output for t in o.inputs)), None)
+                if (reader is not None and not isinstance(reader, _FusedOp)
+                        and getattr(reader.node.layer, "is_weighted_sum", False) and len(reader.inputs) == 2
+                        and reader.inputs[0] is op.output and reader.inputs[1] is not op.output
+                        and blend_audio_source(op.node.layer, xs[0])):
+                    deferred[id(op.output)] = (op.node.layer, op.act_node.layer.alpha_value, xs[0])
+                    for t in op.inputs:
+                        if last_use.get(id(t)) == i and t is not self.output:
+                            vals.pop(id(t), None)
+                    continue
             if (not save and Model.use_conv_chains and not isinstance(op, _FusedOp) and op.act_node is not None
                     and K.bf16_enabled() and xs[0].dtype == torch.float32 and i + 1 < len(plan)):
                 # the from-audio convolution and the 3x3 convolution behind it: the 128-channel tensor between
@@ -455,9 +481,22 @@ class Model:
                 if (not isinstance(nxt, _FusedOp) and getattr(nxt.node.layer, "is_weighted_sum", False)
                         and len(nxt.inputs) == 2 and nxt.inputs[1] is op.output and nxt.inputs[0] is not op.output
                         and n_consumers.get(id(op.output), 0) == 1 and op.output is not self.output
-                        and id(nxt.inputs[0]) in vals):
-                    from .layers import conv_blend_eligible, conv_blend_forward
-                    old = vals[id(nxt.inputs[0])]
+                        and (id(nxt.inputs[0]) in vals or id(nxt.inputs[0]) in deferred)):
+                    from .layers import conv_blend_eligible, conv_blend_forward, conv_blend_audio_eligible, \
+                        conv_blend_audio_forward
+                    src = deferred.get(id(nxt.inputs[0]))
+                    if src is not None and conv_blend_audio_eligible(op.node.layer, xs[0], src[2]):
+                        del deferred[id(nxt.inputs[0])]
+                        vals[id(nxt.output)] = conv_blend_audio_forward(op.node.layer, op.act_node.layer.alpha_value,
+                                                                        xs[0], src[0], src[1], src[2],
+                                                                        nxt.node.layer.alpha.value())
+                        for j, o_ in ((i, op), (i + 1, nxt)):
+                            for t in o_.inputs:
+                                if last_use.get(id(t)) == j and t is not self.output:
+                                    vals.pop(id(t), None)
+                        skip = i + 1
+                        continue
+                    old = value_of(nxt.inputs[0])
                     if conv_blend_eligible(op.node.layer, xs[0], old):
                         vals[id(nxt.output)] = conv_blend_forward(op.node.layer, op.act_node.layer.alpha_value, xs[0],
                                                                   old, nxt.node.layer.alpha.value())
@@ -523,7 +562,7 @@ class Model:
             for t in op.inputs:
                 if last_use.get(id(t)) == i and t is not self.output:
                     vals.pop(id(t), None)
-        return vals[id(self.output)], tape
+        return value_of(self.output), tape
 
     def __call__(self, x, training: bool = False):
         if isinstance(x, KTensor):

@@ -262,6 +262,34 @@ def conv_blend_forward(conv, act_alpha, x, old, alpha):
     return y
 
 
+def blend_audio_source(conv, x) -> bool:
+    """`conv` (followed by a SoftRectifier) is a from-audio layer the bf16 path runs on mgx_pointwise2_bf16_fwd: its
+    output can be left to the epilogue of the blend that reads it."""
+    if not isinstance(conv, Conv2D) or x.dim() != 4 or x.dtype != torch.float32 or not x.is_contiguous():
+        return False
+    n, h, w, _ = x.shape
+    return conv._bf16_mode(x, n, h, w) == "audio"
+
+
+def conv_blend_audio_eligible(conv, x, audio) -> bool:
+    """`conv` (the 1x1 Conv2D that ends a block, followed by a SoftRectifier) on the bf16 tile kernel with 128
+    filters, and `audio` the float32 (n, h, w, 2) input of the from-audio layer whose output the blend would read."""
+    if not isinstance(conv, Conv2D) or x.dim() != 4 or conv.kernel_size != (1, 1) or conv.strides != (1, 1):
+        return False
+    n, h, w, _ = x.shape
+    if x.dtype != torch.bfloat16 or conv.filters != 128 or tuple(audio.shape) != (n, h, w, 2):
+        return False
+    return K.bf16_enabled() and conv._bf16_mode(x, n, h, w) == "conv"
+
+
+def conv_blend_audio_forward(conv, act_alpha, x, audio_conv, audio_alpha, audio, alpha):
+    n, h, w, _ = x.shape
+    y = K.empty((n, h, w, conv.filters), dtype=torch.bfloat16)
+    ops.conv1x1_blend_audio_bf16(conv._desc("f", n, h, w), x, conv.kernel.value(), conv.bias.value(), audio,
+                                 audio_conv.kernel.value(), audio_conv.bias.value(), audio_alpha, alpha, y, act_alpha)
+    return y
+
+
 def conv_chain_eligible(layers, x) -> bool:
     """Two or three layers (each followed by a SoftRectifier) as one launch of the chain kernel: Conv2D(32, k x k,
     same) on 32 channels with kernel sizes {3,3,2}, {3,3} or {3,2}, bf16 input, bf16 precision on."""

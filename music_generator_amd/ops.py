@@ -663,6 +663,27 @@ def conv1x1_blend_bf16(d: ConvDesc, x, w, bias, old, alpha, y, act_alpha):
         PROFILER.stop("bconv_kernel<1,1,3>", _conv_flops(d), e0, _conv_bytes_bf16(d, 1, 2))
 
 
+def conv1x1_blend_audio_bf16(d: ConvDesc, x, w, bias, audio, audio_w, audio_b, audio_alpha, alpha, y, act_alpha):
+    """mgx_conv1x1_blend_audio_bf16: y = (1 - alpha) old + alpha act(conv1x1(x)) with old = the from-audio layer
+    (kernel audio_w (2,128), bias audio_b, SoftRectifier audio_alpha) of the float32 audio (n, h, w, 2), re-computed in
+    the epilogue instead of read; x, y bfloat16, alpha on the device."""
+    xe, ye, we = _conv_sizes(d)
+    if x.numel() != xe or y.numel() != ye or w.numel() < we or alpha.numel() != 1 or d.ngemm != 128:
+        raise MgxError("conv1x1_blend_audio_bf16: operand sizes do not match the descriptor")
+    if audio.dtype != torch.float32 or audio.numel() * 64 != ye or audio_w.numel() != 256 or audio_b.numel() != 128:
+        raise MgxError("conv1x1_blend_audio_bf16: audio must be float32 (n, h, w, 2), its kernel (2,128), its bias (128,)")
+    if d.nbias and (bias is None or bias.numel() != d.nbias):
+        raise MgxError("conv1x1_blend_audio_bf16: bias size mismatch")
+    d.accumulate = 0
+    d.act_alpha = float(act_alpha)
+    e0 = PROFILER.start() if PROFILER is not None else None
+    check(_lib().mgx_conv1x1_blend_audio_bf16(C.byref(d), _pb(x), _p(w), _p(bias) if d.nbias else None, _p(audio),
+                                              _p(audio_w), _p(audio_b), float(audio_alpha), _p(alpha), _pb(y),
+                                              K.stream_ptr()), "mgx_conv1x1_blend_audio_bf16")
+    if e0 is not None:
+        PROFILER.stop("bconv_kernel<1,1,5>", _conv_flops(d), e0, _conv_bytes_bf16(d, 1, 1) + audio.numel() * 4)
+
+
 def conv_pair_bf16_supported(n, h, w, kb) -> bool:
     return bool(_lib().mgx_conv_pair_bf16_supported(int(n), int(h), int(w), int(kb)))
 

@@ -1027,9 +1027,9 @@ def test_bf16_discriminator_forward_with_and_without_chains(bf16_precision):
     real, _ = R.synthetic_inputs(3, 4, seed=2)
     x = torch.from_numpy(real).cuda()
     calls, blends = [], []
-    orig, orig_blend = ops.conv_chain_bf16, ops.conv1x1_blend_bf16
+    orig, orig_blend = ops.conv_chain_bf16, ops.conv1x1_blend_audio_bf16
     ops.conv_chain_bf16 = lambda *a, **k: (calls.append(tuple(a[4])), orig(*a, **k))[1]
-    ops.conv1x1_blend_bf16 = lambda *a, **k: (blends.append(1), orig_blend(*a, **k))[1]
+    ops.conv1x1_blend_audio_bf16 = lambda *a, **k: (blends.append(1), orig_blend(*a, **k))[1]
     chains, taped_chains = Model.use_conv_chains, Model.use_taped_chains
     try:
         Model.use_conv_chains = True
@@ -1059,10 +1059,43 @@ def test_bf16_discriminator_forward_with_and_without_chains(bf16_precision):
         Model.use_conv_chains = chains
         Model.use_taped_chains = taped_chains
         ops.conv_chain_bf16 = orig
-        ops.conv1x1_blend_bf16 = orig_blend
+        ops.conv1x1_blend_audio_bf16 = orig_blend
     assert n_chains >= 6 and set(calls) == {(3, 2), (3, 3, 2), (3, 3)}, calls
-    assert len(blends) == 1            # the fade-in blend of the top block ran in the 1x1 convolution's epilogue
+    # the fade-in blend of the top block ran in the 1x1 convolution's epilogue, its other input (the old stage's
+    # from-audio layer on the pooled audio) re-computed there
+    assert len(blends) == 1
     assert torch.equal(y0, y1), (y0, y1)
+
+
+@pytest.mark.parametrize("n,h,w", [(2, 8, 100), (3, 16, 70), (1, 32, 45), (5, 16, 1500)])
+@pytest.mark.parametrize("alpha", [0.0, 0.37, 1.0])
+def test_bf16_conv1x1_blend_audio_equals_three_launches(n, h, w, alpha):
+    """mgx_conv1x1_blend_audio_bf16 (the blend's first input re-computed from the pooled audio in the epilogue) against
+    mgx_pointwise2_bf16_fwd + mgx_conv_gemm_bf16 + mgx_weighted_sum_bf16_fwd: bit for bit, both tile shapes, ragged
+    widths, audio values large enough to saturate the activation."""
+    M.clear_session()
+    conv = L.Conv2D(128, (1, 1), padding="same", kernel_initializer="he_normal")
+    conv(Input(shape=(h, w, 32)))
+    fa = L.Conv2D(128, (1, 1), padding="same", kernel_initializer="he_normal")
+    fa(Input(shape=(h, w, 2)))
+    rng = np.random.default_rng(n * 1000 + h + w + 7)
+    conv.bias.assign(rng.uniform(-0.5, 0.5, (128,)).astype(np.float32))
+    fa.bias.assign(rng.uniform(-0.5, 0.5, (128,)).astype(np.float32))
+    x = _dev_b(rng.uniform(-1, 1, (n, h, w, 32)))
+    audio = torch.from_numpy(rng.uniform(-3, 3, (n, h, w, 2)).astype(np.float32)).cuda()
+    al = torch.tensor([alpha], device="cuda")
+    old = torch.empty((n, h, w, 128), dtype=torch.bfloat16, device="cuda")
+    mid = torch.empty_like(old)
+    want = torch.empty_like(old)
+    ops.pointwise2_bf16_fwd(audio, fa.kernel.value(), fa.bias.value(), old, None, n * h * w, 20000.0)
+    ops.conv_gemm_bf16(conv._desc("f", n, h, w), x, conv.kernel.value(), conv.bias.value(), mid, act_alpha=90000.0)
+    ops.weighted_sum_bf16_fwd(old, mid, al, want)
+    got = torch.full_like(want, float("nan"))
+    ops.conv1x1_blend_audio_bf16(conv._desc("f", n, h, w), x, conv.kernel.value(), conv.bias.value(), audio,
+                                 fa.kernel.value(), fa.bias.value(), 20000.0, al, got, 90000.0)
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(got.float()).all()), "positions left unwritten"
+    assert torch.equal(got.view(torch.int16), want.view(torch.int16)), float((got.float() - want.float()).abs().max())
 
 
 @pytest.mark.parametrize("n,h,w", [(2, 8, 100), (3, 16, 70), (1, 32, 45), (5, 16, 1500)])
