@@ -142,6 +142,20 @@ def _is_instance(table_key, kernel):
     return tk == kernel or tk.startswith(kernel + "<") or (kernel.endswith(">") and tk.startswith(kernel[:-1] + ","))
 
 
+# A launch-profiler key that stands for one library call issuing several kernels: the kernels it covers
+KERNEL_FAMILIES = {
+    "gblock_wgrad_bf16_kernel<*>": ("gblock_lean_branch_kernel", "gblock_lean_tail_kernel", "gblock_wgrad_bf16_kernel",
+                                    "gblock_unpack_kernel"),
+}
+
+
+def _members(names, kernel):
+    fam = KERNEL_FAMILIES.get(kernel)
+    if fam is None:
+        return [k for k in names if _is_instance(k, kernel)]
+    return [k for k in names if any(_is_instance(k, m) for m in fam)]
+
+
 def measured_traffic(kernel, workload):
     """HBM bytes per launch of `kernel` from the committed PMC passes (profiles/pmc_traffic.json:
     2 x FETCH_SIZE + WRITE_SIZE of separate rocprofv3 --pmc runs of the same workload), or None
@@ -156,8 +170,10 @@ def measured_traffic(kernel, workload):
     entry = wl.get(kernel)
     if entry:
         return entry["hbm_bytes_per_launch"]
-    inst = [e for k, e in wl.items() if isinstance(e, dict) and _is_instance(k, kernel)]
-    n = sum(e["launches_per_step"] for e in inst)
+    inst = [wl[k] for k in _members([k for k, e in wl.items() if isinstance(e, dict)], kernel)]
+    # a family: bytes of all its kernels per library call (every member is launched once or more per call)
+    n = max((e["launches_per_step"] for e in inst), default=0) if kernel in KERNEL_FAMILIES else \
+        sum(e["launches_per_step"] for e in inst)
     return round(sum(e["hbm_bytes_per_launch"] * e["launches_per_step"] for e in inst) / n) if n else None
 
 
@@ -170,7 +186,8 @@ def measured_mfma_busy(kernel, digest):
             rows = json.load(f)["kernels"]
     except (OSError, ValueError, KeyError):
         return None
-    inst = [r for r in rows if "mfma_busy_frac" in r and _is_instance(r["kernel"], kernel)]
+    names = set(_members([r["kernel"] for r in rows], kernel))
+    inst = [r for r in rows if "mfma_busy_frac" in r and r["kernel"] in names]
     t = sum(r["calls"] * r["avg_us"] for r in inst)
     return round(sum(r["mfma_busy_frac"] * r["calls"] * r["avg_us"] for r in inst) / t, 4) if t else None
 
@@ -228,7 +245,7 @@ def progress(msg):
 T_START = time.perf_counter()
 
 
-C3_DIGEST = "r3_c3" if os.path.exists(os.path.join(ROOT, "profiles", "r3_c3_digest.json")) else "r2_c3"
+C3_DIGEST = next((d for d in ("r3d_c3", "r3_c3", "r2_c3") if os.path.exists(os.path.join(ROOT, "profiles", d + "_digest.json"))), "r2_c3")
 C2_DIGEST = "r3_c2" if os.path.exists(os.path.join(ROOT, "profiles", "r3_c2_digest.json")) else "r2_c2"
 C3_MICRO_BATCH = 4          # samples per micro-batch of the full-resolution step (whole MinibatchStdDev groups)
 
