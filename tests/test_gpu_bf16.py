@@ -998,6 +998,14 @@ def test_bf16_conv_chain_equals_separate_launches(h, w, n, ks):
         assert torch.equal(o.view(torch.int16), ref.view(torch.int16)), "layer %d: %.3e" % (i, float((o.float() - ref.float()).abs().max()))
 
 
+@pytest.mark.parametrize("h,w,n,ks", [(48, 333, 1, (3, 3, 2)), (64, 500, 2, (3, 3)), (100, 64, 2, (3, 2)), (9, 30, 1, (3, 3, 2))])
+def test_bf16_conv_chain_pipelined_variant(h, w, n, ks, monkeypatch):
+    """The opt-in software-pipelined chain kernel (MGX_CHAIN_PIPELINED=1: a layer row's MFMAs interleaved with another
+    row's epilogue, one wave per SIMD) gives the bits of the default kernel, tape-free and taped."""
+    monkeypatch.setenv("MGX_CHAIN_PIPELINED", "1")
+    test_bf16_conv_chain_equals_separate_launches(h, w, n, ks)
+
+
 def test_bf16_conv_chain_rejects_what_it_does_not_serve():
     assert not ops.conv_chain_bf16_supported(1, 16, 64, (3, 3, 3))
     assert not ops.conv_chain_bf16_supported(1, 16, 64, (2, 3))
