@@ -639,7 +639,7 @@ def main():
                                    "_bf16" if args.precision == "bfloat16" else "")
         roof["traffic"] = measured_traffic(key, wl)
         if (stage, fade, args.batch) == (3, True, 64):
-            roof["mfma_busy_frac_sq_counters"] = measured_mfma_busy(key, "r2_c2bf16" if args.precision == "bfloat16"
+            roof["mfma_busy_frac_sq_counters"] = measured_mfma_busy(key, "r3d_c2bf16" if args.precision == "bfloat16"
                                                                     else C2_DIGEST)
         if key.startswith("wino3_") and roof["bound"] == "mfma":
             # the kernel's algorithm is Winograd F(2x2,3x3): `achieved` counts the multiply-adds it executes
