@@ -492,14 +492,16 @@ int mgx_gblock_dgrad_bf16_lean(const mgx_gblock_weights* w, void* packt, const f
 int mgx_gblock_wgrad_bf16_lean(const mgx_gblock_weights* w, const void* act, const void* delta, const mgx_gblock_grads* g,
                                void* workspace, int64_t workspace_bytes, int64_t npos, void* stream);
 
-/* Data gradient and weight gradient of one bf16 32 -> 32 'same' convolution (3x3 or 2x2, stride 1) in ONE pass:
+/* Data gradient and weight gradient of one bf16 'same' convolution (32 -> 32 channels 3x3 or 2x2, or 128 -> 32
+ * channels 3x3; stride 1) in ONE pass:
  * the calls mgx_conv_gemm_bf16 (data-gradient descriptor, ymul = x, act_alpha) and mgx_conv_wgrad_bf16 of the same
  * layer read the same two tensors, the layer input x (= the stored output of the layer before it) and g, the
  * gradient with respect to this layer's pre-activation (tf.GradientTape through Conv2D + SoftRectifier,
  * models.py:118, 256-281).  `d` is the layer's FORWARD descriptor, `w` its kernel (Keras layout); dw / dbias are
  * ADDED to as by mgx_conv_wgrad_bf16; dx (bf16, shape of x) receives the input gradient, multiplied by the
  * derivative 1 - tanh^2 + 1/act_alpha recovered from x when act_alpha > 0 (x is then the output of a SoftRectifier
- * layer).  128 B read + 64 B written per position instead of 384.  Workspace: mgx_conv_bwd_bf16_workspace(d)
+ * layer).  128 B read + 64 B written per position instead of 384 (320 + 256 instead of 896 from 128 channels).
+ * Workspace: mgx_conv_bwd_bf16_workspace(d)
  * bytes; fixed-order reduction, bitwise reproducible. */
 int mgx_conv_bwd_bf16_supported(const mgx_conv_desc* d);
 int64_t mgx_conv_bwd_bf16_workspace(const mgx_conv_desc* d);

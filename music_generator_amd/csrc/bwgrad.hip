@@ -273,25 +273,29 @@ __device__ __forceinline__ void static_for(F&& f) {
     }
 }
 
-template <int KH, int KW>
+// CIN = 128 (the block's first 3x3 convolution, 128 -> 32): the tile is 4 rows x 32 columns, X is staged as four
+// planes of 32 channels, and wave c owns input-channel chunk c for the WHOLE tile: its 32 of the 128 data-gradient
+// channels and its own weight-gradient tiles (no sum over the waves at the end), the G window shared by all four.
+template <int KH, int KW, int CIN>
 struct FGeo {
-    static constexpr int TW = 64;
-    static constexpr int GH = WTH + KH - 1, GW = TW + KW - 1;
-    static constexpr int GPIX = GH * GW, XPIX = WTH * TW, TAPS = KH * KW;
-    static constexpr int LDS = 2 * (GPIX + XPIX) * 64;
+    static constexpr int NCH = CIN / 32;
+    static constexpr int TW = CIN == 128 ? 32 : 64, TH = CIN == 128 ? 4 : WTH;
+    static constexpr int GH = TH + KH - 1, GW = TW + KW - 1;
+    static constexpr int GPIX = GH * GW, XPIX = TH * TW, TAPS = KH * KW;
+    static constexpr int LDS = 2 * (GPIX + NCH * XPIX) * 64;
 };
 
 __device__ __forceinline__ int sw_off(int p, int c16) { return p * 64 + ((c16 ^ ((p >> 2) & 3)) << 4); }
 
-template <int KH, int KW, bool ACT>
+template <int KH, int KW, bool ACT, int CIN>
 __global__ __launch_bounds__(256, 1) void bbwd_kernel(mgx_conv_desc d, const bf16_t* __restrict__ x,
                                                       const bf16_t* __restrict__ g, const float* __restrict__ w,
                                                       bf16_t* __restrict__ dx, float* __restrict__ partial, long ntiles,
                                                       int tiles_h, int tiles_w, float act_alpha) {
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
-    using G = FGeo<KH, KW>;
-    constexpr int TW = G::TW, GW = G::GW, GPIX = G::GPIX, XPIX = G::XPIX, TAPS = G::TAPS;
-    constexpr int GITER = (GPIX * 4 + 255) / 256, XITER = (XPIX * 4 + 255) / 256;
+    using G = FGeo<KH, KW, CIN>;
+    constexpr int TW = G::TW, TH = G::TH, NCH = G::NCH, GW = G::GW, GPIX = G::GPIX, XPIX = G::XPIX, TAPS = G::TAPS;
+    constexpr int GITER = (GPIX * 4 + 255) / 256, XITER = (XPIX * NCH * 4 + 255) / 256;
     // A staged row of the G window is GW positions of 64 B; the swizzle of a position's four 16-byte chunks is keyed by
     // its COLUMN (bits 2-3), so a read's address is a per-lane column term (computed once for the launch) plus a
     // term that is uniform over the wave (buffer, row, 32-column block) plus a constant (kernel row, k-step).
@@ -301,10 +305,11 @@ __global__ __launch_bounds__(256, 1) void bbwd_kernel(mgx_conv_desc d, const bf1
     const int r = lane & 31, h = lane >> 5;
     const int H = d.hin, W = d.win;
     const int slot = blockIdx.x, nslots = gridDim.x;
+    const int cch = CIN == 128 ? wvs : 0;               // the wave's input-channel chunk
     constexpr int PT = (KH - 1) / 2, PL = (KW - 1) / 2;       // 'same' padding in front (Keras: the extra row of an even kernel goes behind)
     constexpr int gy0 = KH - 1 - PT, gx0 = KW - 1 - PL;       // rows / columns of halo in front of the tile
     unsigned char* gbuf = lds;                       // [2][GPIX][64 B]
-    unsigned char* xbuf = lds + 2 * GPIX * 64;       // [2][XPIX][64 B]
+    unsigned char* xbuf = lds + 2 * GPIX * 64;       // [2][NCH planes][XPIX][64 B]
 
     auto tile_of = [&](long t, long& img, int& h0, int& w0) {
         const unsigned per_img = (unsigned)(tiles_h * tiles_w);
@@ -313,7 +318,7 @@ __global__ __launch_bounds__(256, 1) void bbwd_kernel(mgx_conv_desc d, const bf1
         const unsigned rem = tu - im * per_img;
         const unsigned th = rem / (unsigned)tiles_w;
         img = im;
-        h0 = (int)th * WTH;
+        h0 = (int)th * TH;
         w0 = (int)(rem - th * tiles_w) * TW;
     };
     const int q4 = tid & 3;
@@ -334,15 +339,16 @@ __global__ __launch_bounds__(256, 1) void bbwd_kernel(mgx_conv_desc d, const bf1
             const unsigned off = ok ? (unsigned)(((ty * W + (tx + wb)) * 32 + q4 * 8) * 2) : 0xfffffff0u;
             sg[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rg, off, 0, 0));
         }
-        const long xband = ((img * H + h0) * (long)W) * 32;
+        // X tile: 4 NCH 16-byte pieces a position, consecutive threads on consecutive pieces
+        const long xband = ((img * H + h0) * (long)W) * CIN;
         const __amdgpu_buffer_rsrc_t rx =
-            __builtin_amdgcn_make_buffer_rsrc((void*)(x + xband), 0, (unsigned)WTH * W * 64u, 0x00020000);
+            __builtin_amdgcn_make_buffer_rsrc((void*)(x + xband), 0, (unsigned)TH * W * (CIN * 2u), 0x00020000);
 #pragma unroll
         for (int i = 0; i < XITER; ++i) {
-            const int px = (tid >> 2) + 64 * i;
+            const int pc = tid + 256 * i, px = pc / (4 * NCH), sub = pc - px * (4 * NCH);
             const int ty = px / TW, tx = px - ty * TW;
-            const bool ok = (unsigned)(ty + h0) < (unsigned)H && (unsigned)(tx + w0) < (unsigned)W;
-            const unsigned off = ok ? (unsigned)(((ty * W + (tx + w0)) * 32 + q4 * 8) * 2) : 0xfffffff0u;
+            const bool ok = px < XPIX && (unsigned)(ty + h0) < (unsigned)H && (unsigned)(tx + w0) < (unsigned)W;
+            const unsigned off = ok ? (unsigned)(((ty * W + (tx + w0)) * CIN + sub * 8) * 2) : 0xfffffff0u;
             sx[i] = __builtin_bit_cast(u32x4, __builtin_amdgcn_raw_buffer_load_b128(rx, off, 0, 0));
         }
     };
@@ -355,8 +361,9 @@ __global__ __launch_bounds__(256, 1) void bbwd_kernel(mgx_conv_desc d, const bf1
         }
 #pragma unroll
         for (int i = 0; i < XITER; ++i) {
-            const int px = (tid >> 2) + 64 * i;
-            *(u32x4*)(xbuf + b * XPIX * 64 + sw_off(px, q4)) = sx[i];
+            const int pc = tid + 256 * i, px = pc / (4 * NCH), sub = pc - px * (4 * NCH);
+            if (256 * (i + 1) <= XPIX * NCH * 4 || px < XPIX)
+                *(u32x4*)(xbuf + (b * NCH + (sub >> 2)) * XPIX * 64 + sw_off(px, sub & 3)) = sx[i];
         }
     };
 
@@ -366,7 +373,7 @@ __global__ __launch_bounds__(256, 1) void bbwd_kernel(mgx_conv_desc d, const bf1
     for (int tap = 0; tap < TAPS; ++tap)
 #pragma unroll
         for (int ks = 0; ks < 2; ++ks) {
-            const float* p = w + tap * 1024 + r * 32 + 16 * ks + 8 * h;
+            const float* p = w + tap * (CIN * 32) + (cch * 32 + r) * 32 + 16 * ks + 8 * h;
             const f32x4 a = *(const f32x4*)p, b = *(const f32x4*)(p + 4);
             wf[tap][ks] = (u32x4){bf_pack(a[0], a[1]), bf_pack(a[2], a[3]), bf_pack(b[0], b[1]), bf_pack(b[2], b[3])};
         }
@@ -422,11 +429,11 @@ __global__ __launch_bounds__(256, 1) void bbwd_kernel(mgx_conv_desc d, const bf1
         // the last MFMAs of this one), and the epilogue of the block's data gradient (lane exchange, activation
         // derivative, rounding, stores) in pieces between the MFMAs of its weight gradient.  The scheduling barriers
         // pin that order.
-        const int ugb = cur * GPIX * 64, uxb = (2 * GPIX + cur * XPIX) * 64;        // uniform terms of the current buffers
+        const int ugb = cur * GPIX * 64, uxb = (2 * GPIX + (cur * NCH + cch) * XPIX) * 64;     // uniform terms of the current buffers
         constexpr int NJ = 2 * KW, NSTAGE = 3 * KH, NWM = 2 * (TAPS + 1), NPIECE = 19, WM0 = 2;
         u32x4 dq[2][NJ], wq[2][KW], af[2], yv[2], o[2];
         f32x16 dacc;
-        int ug = ugb + 2 * wvs * ROWB, ux = 0, ugn = ug, oh = 0, ow = 0;
+        int ug = ugb + (CIN == 128 ? 0 : 2 * wvs) * ROWB, ux = 0, ugn = ug, oh = 0, ow = 0;
         // item I of the LDS reads that stage S works on (S = NSTAGE: stage 0 of the next block)
         auto prep = [&](auto S_, auto I_) {
             constexpr int S = decltype(S_)::value, i = decltype(I_)::value;
@@ -467,7 +474,7 @@ __global__ __launch_bounds__(256, 1) void bbwd_kernel(mgx_conv_desc d, const bf1
                     }
                     o[half][q] = bf_pack(v0, v1);
                 } else if (oh < H && ow < W) {
-                    bf16_t* dst = dx + (((img * H + oh) * (long)W + ow) * 32);
+                    bf16_t* dst = dx + (((img * H + oh) * (long)W + ow) * CIN) + cch * 32;
                     *(u32x4*)(dst + 16 * half + 8 * h) = o[half];
                 }
             }
@@ -504,11 +511,11 @@ __global__ __launch_bounds__(256, 1) void bbwd_kernel(mgx_conv_desc d, const bf1
         static_for<0, NJ>([&](auto I_) { prep(std::integral_constant<int, NSTAGE>{}, I_); });
 #pragma unroll 1
         for (int it = 0; it < 4; ++it) {
-            const int wr = 2 * wvs + (it >> 1), col0 = 32 * (it & 1);
+            const int wr = CIN == 128 ? it : 2 * wvs + (it >> 1), col0 = CIN == 128 ? 0 : 32 * (it & 1);
             const int itn = (it + 1) & 3;                                      // the last block prepares the first again: unused, in range
             ug = ugb + wr * ROWB + col0 * 64;
             ux = uxb + (wr * TW + col0) * 64;
-            ugn = ugb + (2 * wvs + (itn >> 1)) * ROWB + 32 * (itn & 1) * 64;
+            ugn = CIN == 128 ? ugb + itn * ROWB : ugb + (2 * wvs + (itn >> 1)) * ROWB + 32 * (itn & 1) * 64;
             oh = h0 + wr;
             ow = w0 + col0 + r;
 #pragma unroll
@@ -525,6 +532,15 @@ __global__ __launch_bounds__(256, 1) void bbwd_kernel(mgx_conv_desc d, const bf1
         t = tn;
     }
 
+    if constexpr (CIN == 128) {
+        // every wave holds the tiles of its own input-channel chunk: slab (slot, chunk) of the workspace
+        float* dst = partial + ((long)(slot * NCH + cch) * (TAPS + 1)) * 1024;
+#pragma unroll
+        for (int a = 0; a <= TAPS; ++a)
+#pragma unroll
+            for (int i = 0; i < 16; ++i) dst[(a * 16 + i) * 64 + lane] = acc[a][i];
+        return;
+    }
     // ---- add the four waves in fixed order: (w0 + w2) + (w1 + w3), through LDS ----
     float* red = (float*)lds;                           // [2][TAPS+1][16][64] floats <= 80 KB
     __syncthreads();
@@ -582,24 +598,24 @@ int launch_w(const mgx_conv_desc& d, const bf16_t* x, const bf16_t* g, float* dw
 
 int wgrad_taps(const mgx_conv_desc& d) { return d.kh * d.kw; }
 
-template <int KH, int KW>
+template <int KH, int KW, int CIN>
 int launch_f(const mgx_conv_desc& d, const bf16_t* x, const bf16_t* g, const float* w, float* dw, float* db, bf16_t* dx,
              float* partial, float act_alpha, hipStream_t st) {
-    using G = FGeo<KH, KW>;
-    const int tiles_h = (d.hout + WTH - 1) / WTH, tiles_w = (d.wout + G::TW - 1) / G::TW;
+    using G = FGeo<KH, KW, CIN>;
+    const int tiles_h = (d.hout + G::TH - 1) / G::TH, tiles_w = (d.wout + G::TW - 1) / G::TW;
     const long ntiles = (long)d.nimg * tiles_h * tiles_w;
     if (ntiles <= 0 || ntiles >= (1L << 31)) return MGX_ERR_ARG;
-    const void* fn = act_alpha > 0.f ? (const void*)bbwd_kernel<KH, KW, true> : (const void*)bbwd_kernel<KH, KW, false>;
+    const void* fn = act_alpha > 0.f ? (const void*)bbwd_kernel<KH, KW, true, CIN> : (const void*)bbwd_kernel<KH, KW, false, CIN>;
     if (hipFuncSetAttribute(fn, hipFuncAttributeMaxDynamicSharedMemorySize, G::LDS) != hipSuccess) return MGX_ERR_LAUNCH;
     if (act_alpha > 0.f)
-        hipLaunchKernelGGL((bbwd_kernel<KH, KW, true>), dim3(WGRID), dim3(256), G::LDS, st, d, x, g, w, dx, partial, ntiles,
-                           tiles_h, tiles_w, act_alpha);
+        hipLaunchKernelGGL((bbwd_kernel<KH, KW, true, CIN>), dim3(WGRID), dim3(256), G::LDS, st, d, x, g, w, dx, partial,
+                           ntiles, tiles_h, tiles_w, act_alpha);
     else
-        hipLaunchKernelGGL((bbwd_kernel<KH, KW, false>), dim3(WGRID), dim3(256), G::LDS, st, d, x, g, w, dx, partial, ntiles,
-                           tiles_h, tiles_w, act_alpha);
-    const long total = (long)G::TAPS * 1024 + (db ? d.ngemm : 0);
+        hipLaunchKernelGGL((bbwd_kernel<KH, KW, false, CIN>), dim3(WGRID), dim3(256), G::LDS, st, d, x, g, w, dx, partial,
+                           ntiles, tiles_h, tiles_w, act_alpha);
+    const long total = (long)G::NCH * G::TAPS * 1024 + (db ? d.ngemm : 0);
     hipLaunchKernelGGL(bwgrad_reduce_kernel, dim3((unsigned)((total + 63) / 64)), dim3(1024), 0, st, d, partial, dw, db,
-                       WGRID, 1, G::TAPS);
+                       WGRID, G::NCH, G::TAPS);
     return mgx_launch_status();
 }
 
@@ -631,19 +647,22 @@ extern "C" int mgx_conv_wgrad_bf16(const mgx_conv_desc* dp, const void* x, const
     return launch_w<1, 1, false>(d, xb, gb, dw, dbias, part, st);
 }
 
-// The fused backward serves the 3x3 and 2x2 'same' convolutions between 32 and 32 channels, stride 1, weights in
-// the Keras layout of the forward descriptor (tap, input channel, output channel; output channel fastest).
+// The fused backward serves the 3x3 and 2x2 'same' convolutions between 32 and 32 channels and the 3x3 one from 128
+// to 32 channels, stride 1, weights in the Keras layout of the forward descriptor (tap, input channel, output
+// channel; output channel fastest).
 extern "C" int mgx_conv_bwd_bf16_supported(const mgx_conv_desc* d) {
     if (!d || !mgx_conv_bf16_supported(d)) return 0;
-    if (d->cin != 32 || d->ngemm != 32 || d->cout != 32 || d->sh != 1 || d->sw != 1 || d->dkh != 1 || d->dkw != 1 || d->flip)
+    if ((d->cin != 32 && d->cin != 128) || d->ngemm != 32 || d->cout != 32 || d->sh != 1 || d->sw != 1 || d->dkh != 1 ||
+        d->dkw != 1 || d->flip)
         return 0;
-    if (!((d->kh == 3 && d->kw == 3) || (d->kh == 2 && d->kw == 2))) return 0;
+    if (!((d->kh == 3 && d->kw == 3) || (d->kh == 2 && d->kw == 2 && d->cin == 32))) return 0;
     if (d->hin != d->hout || d->win != d->wout || d->pt != (d->kh - 1) / 2 || d->pl != (d->kw - 1) / 2) return 0;
-    return d->wsn == 1 && d->wsk == 32 && d->wtap == 1024;
+    if ((long)(WTH + 2) * d->win * d->cin * 2 >= (1L << 31)) return 0;       // byte offsets inside a tile's band of rows stay in 32 bits
+    return d->wsn == 1 && d->wsk == 32 && d->wtap == 32 * d->cin;
 }
 
 extern "C" int64_t mgx_conv_bwd_bf16_workspace(const mgx_conv_desc* d) {
-    return mgx_conv_bwd_bf16_supported(d) ? mgx_conv_wgrad_bf16_workspace(d) : 0;
+    return mgx_conv_bwd_bf16_supported(d) ? (int64_t)(d->cin / 32) * mgx_conv_wgrad_bf16_workspace(d) : 0;
 }
 
 extern "C" int mgx_conv_bwd_bf16(const mgx_conv_desc* dp, const void* x, const void* g, const float* w, float* dw,
@@ -654,7 +673,9 @@ extern "C" int mgx_conv_bwd_bf16(const mgx_conv_desc* dp, const void* x, const v
     if (dbias && dp->nbias != dp->ngemm) return MGX_ERR_ARG;
     if (!(act_alpha >= 0.f)) return MGX_ERR_ARG;
     hipStream_t st = (hipStream_t)stream;
+    if (dp->cin == 128)
+        return launch_f<3, 3, 128>(*dp, (const bf16_t*)x, (const bf16_t*)g, w, dw, dbias, (bf16_t*)dx, (float*)workspace, act_alpha, st);
     if (dp->kh == 3)
-        return launch_f<3, 3>(*dp, (const bf16_t*)x, (const bf16_t*)g, w, dw, dbias, (bf16_t*)dx, (float*)workspace, act_alpha, st);
-    return launch_f<2, 2>(*dp, (const bf16_t*)x, (const bf16_t*)g, w, dw, dbias, (bf16_t*)dx, (float*)workspace, act_alpha, st);
+        return launch_f<3, 3, 32>(*dp, (const bf16_t*)x, (const bf16_t*)g, w, dw, dbias, (bf16_t*)dx, (float*)workspace, act_alpha, st);
+    return launch_f<2, 2, 32>(*dp, (const bf16_t*)x, (const bf16_t*)g, w, dw, dbias, (bf16_t*)dx, (float*)workspace, act_alpha, st);
 }

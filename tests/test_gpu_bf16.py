@@ -68,6 +68,8 @@ BCONV_CASES = [
     (32, 700, 32, 32, (3, 3), (1, 1), "same", 12),     # 528 tiles: workgroups walk several tiles
     (64, 1500, 32, 32, (3, 3), (1, 1), "same", 4),     # 768 tiles of the fused backward: three per workgroup
     (64, 1500, 32, 32, (2, 2), (1, 1), "same", 4),
+    (18, 333, 128, 32, (3, 3), (1, 1), "same", 3),     # fused backward from 128 channels: ragged 4 x 32 tiles
+    (64, 1000, 128, 32, (3, 3), (1, 1), "same", 1),    # ... 512 tiles, two per workgroup
 ]
 
 
@@ -137,7 +139,7 @@ def test_bf16_conv_forward_dgrad_wgrad(case):
     _close_f(dw.view(layer.kernel.shape) - 0.5, gk.numpy(), "weight gradient", 5e-5)
     _close_f(db + 0.25, gb.numpy(), "bias gradient", 5e-5)
 
-    # both gradients in one pass (32 -> 32 'same' layers): against the oracle and against the two kernels above, with
+    # both gradients in one pass (32 -> 32 'same' layers and the 3x3 one from 128 channels): against the oracle and against the two kernels above, with
     # the derivative recovered from the layer input as the stored output of the layer before, and without it
     if ops.conv_bwd_bf16_supported(fd):
         xact = act_out if act_out.shape == x.shape else x
@@ -161,7 +163,7 @@ def test_bf16_conv_forward_dgrad_wgrad(case):
             assert float(d12.max()) <= 2.0 ** -7 * float(dx1.float().abs().max()), float(d12.max())
             assert float((d12 > 0).float().mean()) < 0.02
     else:
-        assert not (ci == 32 and co == 32 and st == (1, 1))
+        assert not (co == 32 and st == (1, 1) and (ci == 32 or ks == (3, 3)))
     torch.cuda.synchronize()
 
 
