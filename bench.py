@@ -245,7 +245,7 @@ def progress(msg):
 T_START = time.perf_counter()
 
 
-C3_DIGEST = next((d for d in ("r3d_c3", "r3_c3", "r2_c3") if os.path.exists(os.path.join(ROOT, "profiles", d + "_digest.json"))), "r2_c3")
+C3_DIGEST = next((d for d in ("r3e_c3", "r3_c3", "r2_c3") if os.path.exists(os.path.join(ROOT, "profiles", d + "_digest.json"))), "r2_c3")
 C2_DIGEST = "r3_c2" if os.path.exists(os.path.join(ROOT, "profiles", "r3_c2_digest.json")) else "r2_c2"
 C3_MICRO_BATCH = 4          # samples per micro-batch of the full-resolution step (whole MinibatchStdDev groups)
 
