@@ -367,6 +367,16 @@ int mgx_conv_gemm_bf16(const mgx_conv_desc* d, const void* x, const float* w, co
  * descriptor.  Rounded where the two launches it replaces round (results are bit-identical to them). */
 int mgx_conv1x1_blend_bf16(const mgx_conv_desc* d, const void* x, const float* w, const float* bias, const void* old,
                            const float* alpha, void* y, void* stream);
+/* Data gradient of the block's first 3x3 convolution (128 -> 32 channels) and of the from-audio Conv2D(128, 1x1) +
+ * SoftRectifier in front of it (models.py:256-259) in one launch, for backward sweeps that need no weight gradients
+ * (tape.gradient(g_loss, generator variables) through the discriminator, models.py:144): d is the 3x3 layer's
+ * data-gradient descriptor (32 -> 128 channels, d->act_alpha the from-audio layer's alpha), g the gradient with respect
+ * to the 3x3 layer's pre-activation (bf16), y128 the from-audio layer's stored output (bf16), audio_w its kernel
+ * (2, 128); dx (nimg, h, w, 2) float32 receives the gradient of the audio (is added to when accumulate != 0).  The
+ * values mgx_conv_gemm_bf16 (ymul) would store as bf16 are contracted with audio_w in registers: equal to that call
+ * followed by mgx_pointwise_to2_bf16 up to the order of the float32 sums. */
+int mgx_conv_dgrad_to_audio_bf16(const mgx_conv_desc* d, const void* g, const float* w, const void* y128,
+                                 const float* audio_w, float* dx, int accumulate, void* stream);
 /* The same launch with `old` given as the layer that produces it in the fade-in graph (models.py:292-296): the old
  * stage's from-audio Conv2D(128, 1x1) + SoftRectifier(audio_alpha) applied to the average-pooled 2-channel audio
  * (float32, (nimg, h, w, 2) of the output's height and width), kernel audio_w (2, 128) and bias audio_b (128).  Every

@@ -122,6 +122,7 @@ PROTOTYPES = {
     "mgx_conv_bf16_supported": (_I, [_DESC]),
     "mgx_conv_gemm_bf16": (_I, [_DESC, _P, _P, _P, _P, _P, _P, _P]),
     "mgx_conv1x1_blend_bf16": (_I, [_DESC, _P, _P, _P, _P, _P, _P, _P]),
+    "mgx_conv_dgrad_to_audio_bf16": (_I, [_DESC, _P, _P, _P, _P, _P, _I, _P]),
     "mgx_conv1x1_blend_audio_bf16": (_I, [_DESC, _P, _P, _P, _P, _P, _P, _F, _P, _P, _P]),
     "mgx_conv1x1_blend_supported": (_I, [_DESC]),
     "mgx_conv1x1_blend_f32": (_I, [_DESC, _P, _P, _P, _P, _P, _P, _P]),

@@ -24,7 +24,10 @@
 // which the derivative is recovered; plain; or (1x1 kernels, passes that keep no tape) bias + activation followed by
 // the fade-in blend (1 - alpha) old + alpha y of trainer/models.py:30-35 with a bf16 tensor `old` of the output's
 // shape, in place of a WeightedSum launch that would read the activation back; the same with `old` itself re-computed
-// per element from the 2-channel audio it is a 1x1 convolution + activation of (8 bytes a position read instead of 256).
+// per element from the 2-channel audio it is a 1x1 convolution + activation of (8 bytes a position read instead of 256);
+// or (128 output channels, backward passes that need no weight gradients) epilogue 4 followed by the data gradient of
+// the from-audio 1x1 convolution in front: the 128-channel gradient is contracted with that layer's (2, 128) kernel
+// in registers and only the two audio channels are written.
 #include <cstdlib>
 #include "bf16.h"
 #include "../../include/mgx.h"
@@ -48,6 +51,13 @@ struct BlendAudio {
     const float* b;
     float inv_alpha;
 };
+// Epilogue 6: kernel (2, 128) of the from-audio layer whose output this data gradient arrives at, the gradient of
+// its 2-channel float32 input (nimg, h, w, 2), and whether that is added to.
+struct ToAudio {
+    const float* w;
+    float* dx;
+    int accumulate;
+};
 
 template <int KH, int KW, int EPI, int TH, int NT>
 __global__ __launch_bounds__(64 * TH) void bconv_kernel(mgx_conv_desc d, const bf16_t* __restrict__ x,
@@ -55,11 +65,12 @@ __global__ __launch_bounds__(64 * TH) void bconv_kernel(mgx_conv_desc d, const b
                                                        bf16_t* __restrict__ y, bf16_t* __restrict__ dact,
                                                        const bf16_t* __restrict__ ymul, long ntiles, int tiles_h,
                                                        int tiles_w, int gin_w, int scat,
-                                                       const float* __restrict__ blend_alpha, BlendAudio ba) {
+                                                       const float* __restrict__ blend_alpha, BlendAudio ba, ToAudio ta) {
     // EPI: 0 plain, 1 bias + activation (+ derivative), 2 multiply by ymul, 3 = 1 followed by the blend with ymul,
     // 4 multiply by the activation derivative recovered from ymul = the activation's stored OUTPUT (dact_from_y),
-    // 5 = 3 with the blend's other input re-computed from the audio (ba) instead of read from ymul
-    constexpr bool ACT = EPI == 1 || EPI == 3 || EPI == 5, PRE = EPI == 2 || EPI == 3 || EPI == 4;
+    // 5 = 3 with the blend's other input re-computed from the audio (ba) instead of read from ymul,
+    // 6 = 4 contracted with the from-audio kernel (ta): nothing of the output's own shape is written
+    constexpr bool ACT = EPI == 1 || EPI == 3 || EPI == 5, PRE = EPI == 2 || EPI == 3 || EPI == 4 || EPI == 6;
     extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
     constexpr int TW = NT * 32, NTHR = 64 * TH;
     constexpr int IH = TH + KH - 1, IW = TW + KW - 1, TAPS = KH * KW, NPIX = IH * IW;
@@ -151,6 +162,13 @@ __global__ __launch_bounds__(64 * TH) void bconv_kernel(mgx_conv_desc d, const b
     f32x4* fa = (f32x4*)(bl + N);
     if (EPI == 5)
         for (int i = tid; i < 128; i += NTHR) fa[i] = (f32x4){ba.w[i], ba.w[128 + i], ba.b[i], 0.f};
+    // epilogue 6: {w[0][c], w[1][c]} per channel c of the from-audio kernel
+    f32x2* tw = (f32x2*)(bl + N);
+    if (EPI == 6)
+        for (int i = tid; i < 128; i += NTHR) tw[i] = (f32x2){ta.w[i], ta.w[128 + i]};
+    float ta0[NT], ta1[NT];          // the lane's partial sums of the two audio channels over the chunks of a tile
+#pragma unroll
+    for (int nt = 0; nt < NT; ++nt) { ta0[nt] = 0.f; ta1[nt] = 0.f; }
 
     long t = blockIdx.x;
     int oc = 0;
@@ -282,7 +300,7 @@ __global__ __launch_bounds__(64 * TH) void bconv_kernel(mgx_conv_desc d, const b
                     o[i] = bf_pack(a[2 * i] * bf_lo(m0[i]), a[2 * i + 1] * bf_hi(m0[i]));
                     o[4 + i] = bf_pack(a[8 + 2 * i] * bf_lo(m1[i]), a[8 + 2 * i + 1] * bf_hi(m1[i]));
                 }
-            } else if (EPI == 4) {
+            } else if (EPI == 4 || EPI == 6) {
                 const u32x4 m0 = pre_m[nt][0], m1 = pre_m[nt][1];
 #pragma unroll
                 for (int i = 0; i < 4; ++i) {
@@ -290,6 +308,35 @@ __global__ __launch_bounds__(64 * TH) void bconv_kernel(mgx_conv_desc d, const b
                                    a[2 * i + 1] * dact_from_y(bf_hi(m0[i]), inv_alpha, k1));
                     o[4 + i] = bf_pack(a[8 + 2 * i] * dact_from_y(bf_lo(m1[i]), inv_alpha, k1),
                                        a[8 + 2 * i + 1] * dact_from_y(bf_hi(m1[i]), inv_alpha, k1));
+                }
+                if (EPI == 6) {
+                    // the values a store would have rounded to bf16, times the from-audio kernel: channels
+                    // nc_ * 32 + 8h .. + 7 (o[0..3]) and nc_ * 32 + 16 + 8h .. + 7 (o[4..7])
+                    if (nc_ == 0) { ta0[nt] = 0.f; ta1[nt] = 0.f; }
+#pragma unroll
+                    for (int half = 0; half < 2; ++half)
+#pragma unroll
+                        for (int i = 0; i < 4; ++i) {
+                            const int c = nc_ * 32 + 16 * half + 8 * h + 2 * i;
+                            const f32x2 wa = tw[c], wb = tw[c + 1];
+                            const float lo = bf_lo(o[4 * half + i]), hi = bf_hi(o[4 * half + i]);
+                            ta0[nt] = __builtin_fmaf(hi, wb[0], __builtin_fmaf(lo, wa[0], ta0[nt]));
+                            ta1[nt] = __builtin_fmaf(hi, wb[1], __builtin_fmaf(lo, wa[1], ta1[nt]));
+                        }
+                    if (nc_ == nchunks - 1) {
+                        // the two lanes of a position hold the two halves of its channels
+                        const float s0 = ta0[nt] + __shfl_xor(ta0[nt], 32), s1 = ta1[nt] + __shfl_xor(ta1[nt], 32);
+                        long img; int h0, w0_;
+                        tile_of(t_, img, h0, w0_);
+                        const int row = h0 + wvs, col = w0_ + nt * 32 + r;
+                        if (h == 0 && row < H && col < W) {
+                            float* dst = ta.dx + ((img * H + row) * (long)W + col) * 2;
+                            f32x2 v = {s0, s1};
+                            if (ta.accumulate) { const f32x2 old = *(const f32x2*)dst; v[0] += old[0]; v[1] += old[1]; }
+                            *(f32x2*)dst = v;
+                        }
+                    }
+                    continue;
                 }
             } else {
 #pragma unroll
@@ -347,16 +394,18 @@ __global__ __launch_bounds__(64 * TH) void bconv_kernel(mgx_conv_desc d, const b
 template <int KH, int KW, int TH, int NT>
 int launch_shape(const mgx_conv_desc& d, const bf16_t* x, const float* w, const float* bias, bf16_t* y, bf16_t* dact,
                  const bf16_t* ymul, hipStream_t st, int gin_w, int scat, const float* blend_alpha = nullptr,
-                 const BlendAudio* audio = nullptr) {
+                 const BlendAudio* audio = nullptr, const ToAudio* to_audio = nullptr) {
     constexpr int TW = NT * 32;
     const int tiles_h = (d.hin + TH - 1) / TH, tiles_w = (d.win + TW - 1) / TW;
     const long ntiles = (long)d.nimg * tiles_h * tiles_w;
     if (ntiles <= 0 || ntiles >= (1L << 31)) return MGX_ERR_ARG;
     const unsigned grid = (unsigned)(ntiles < 256 ? ntiles : 256);
-    const int lds = KH * KW * d.cin * d.ngemm * 2 + 2 * npix<KH, KW, TH, NT>() * 64 + d.ngemm * 4 + (audio ? 128 * 16 : 0);
+    const int lds = KH * KW * d.cin * d.ngemm * 2 + 2 * npix<KH, KW, TH, NT>() * 64 + d.ngemm * 4 +
+                    (audio ? 128 * 16 : 0) + (to_audio ? 128 * 8 : 0);
     if (lds > 160 * 1024) return MGX_ERR_ARG;
     const BlendAudio ba = audio ? *audio : BlendAudio{nullptr, nullptr, nullptr, 0.f};
-    const int epi = blend_alpha != nullptr ? (audio ? 5 : 3)
+    const ToAudio ta = to_audio ? *to_audio : ToAudio{nullptr, nullptr, 0};
+    const int epi = to_audio ? 6 : blend_alpha != nullptr ? (audio ? 5 : 3)
                     : (ymul != nullptr ? (d.act_alpha > 0.f ? 4 : 2) : ((d.nbias > 0 || d.act_alpha > 0.f) ? 1 : 0));
 #define MGX_B(E)                                                                                                     \
     do {                                                                                                             \
@@ -364,13 +413,16 @@ int launch_shape(const mgx_conv_desc& d, const bf16_t* x, const float* w, const 
                                 hipFuncAttributeMaxDynamicSharedMemorySize, lds) != hipSuccess)                      \
             return MGX_ERR_LAUNCH;                                                                                   \
         hipLaunchKernelGGL((bconv_kernel<KH, KW, E, TH, NT>), dim3(grid), dim3(64 * TH), lds, st, d, x, w, bias, y,  \
-                           dact, ymul, ntiles, tiles_h, tiles_w, gin_w, scat, blend_alpha, ba);                      \
+                           dact, ymul, ntiles, tiles_h, tiles_w, gin_w, scat, blend_alpha, ba, ta);                  \
     } while (0)
     if (epi == 3) {
         if constexpr (KH == 1 && KW == 1) MGX_B(3);
         else return MGX_ERR_ARG;
     } else if (epi == 5) {
         if constexpr (KH == 1 && KW == 1) MGX_B(5);
+        else return MGX_ERR_ARG;
+    } else if (epi == 6) {
+        if constexpr (KH == 3 && KW == 3) MGX_B(6);
         else return MGX_ERR_ARG;
     } else if (epi == 4) MGX_B(4);
     else if (epi == 2) MGX_B(2);
@@ -385,12 +437,12 @@ int launch_shape(const mgx_conv_desc& d, const bf16_t* x, const float* w, const 
 template <int KH, int KW>
 int launch_b(const mgx_conv_desc& d, const bf16_t* x, const float* w, const float* bias, bf16_t* y, bf16_t* dact,
              const bf16_t* ymul, hipStream_t st, int gin_w, int scat, const float* blend_alpha = nullptr,
-             const BlendAudio* audio = nullptr) {
+             const BlendAudio* audio = nullptr, const ToAudio* to_audio = nullptr) {
     const int lds16 = KH * KW * d.cin * d.ngemm * 2 + 2 * npix<KH, KW, 16, 1>() * 64 + d.ngemm * 4;
     bool tall = d.hin >= 16 && d.hin % 16 == 0 && lds16 <= 160 * 1024;
     if (const char* e = getenv("MGX_BCONV_TILE")) tall = e[0] == '1' && lds16 <= 160 * 1024;
-    if (tall) return launch_shape<KH, KW, 16, 1>(d, x, w, bias, y, dact, ymul, st, gin_w, scat, blend_alpha, audio);
-    return launch_shape<KH, KW, 8, 2>(d, x, w, bias, y, dact, ymul, st, gin_w, scat, blend_alpha, audio);
+    if (tall) return launch_shape<KH, KW, 16, 1>(d, x, w, bias, y, dact, ymul, st, gin_w, scat, blend_alpha, audio, to_audio);
+    return launch_shape<KH, KW, 8, 2>(d, x, w, bias, y, dact, ymul, st, gin_w, scat, blend_alpha, audio, to_audio);
 }
 
 }  // namespace
@@ -462,4 +514,22 @@ extern "C" int mgx_conv1x1_blend_audio_bf16(const mgx_conv_desc* dp, const void*
     if (!(audio_alpha > 0.f)) return MGX_ERR_ARG;
     const BlendAudio ba = {audio, audio_w, audio_b, 1.0f / audio_alpha};
     return launch_b<1, 1>(*dp, (const bf16_t*)x, w, bias, (bf16_t*)y, nullptr, nullptr, (hipStream_t)stream, 0, 0, alpha, &ba);
+}
+
+// Data gradient of the block's first 3x3 convolution (128 -> 32 channels) AND of the from-audio 1x1 convolution +
+// SoftRectifier in front of it (trainer/models.py:256-259), for backward passes that need no weight gradients (the
+// generator step's sweep through the discriminator, models.py:144): `d` is the 3x3 layer's data-gradient descriptor
+// (32 -> 128 channels), g the gradient with respect to its pre-activation, `y128` the from-audio layer's stored
+// OUTPUT (the derivative is recovered from it, d->act_alpha that layer's alpha), audio_w its kernel (2, 128); dx
+// (nimg, h, w, 2) float32 receives (accumulate: is added) the gradient of the audio.  What mgx_conv_gemm_bf16 (ymul)
+// would store as bf16 is contracted with audio_w in registers instead: the 128-channel gradient is never written.
+extern "C" int mgx_conv_dgrad_to_audio_bf16(const mgx_conv_desc* dp, const void* g, const float* w, const void* y128,
+                                            const float* audio_w, float* dx, int accumulate, void* stream) {
+    if (!dp || !g || !w || !y128 || !audio_w || !dx || !mgx_conv_bf16_supported(dp)) return MGX_ERR_ARG;
+    if (dp->kh != 3 || dp->kw != 3 || dp->sh != 1 || dp->dkh != 1 || dp->accumulate || dp->cin != 32 || dp->ngemm != 128 ||
+        dp->nbias > 0 || !(dp->act_alpha > 0.f))
+        return MGX_ERR_ARG;
+    const ToAudio ta = {audio_w, dx, accumulate ? 1 : 0};
+    return launch_b<3, 3>(*dp, (const bf16_t*)g, w, nullptr, nullptr, nullptr, (const bf16_t*)y128, (hipStream_t)stream, 0, 0,
+                          nullptr, nullptr, &ta);
 }

@@ -638,6 +638,9 @@ class Model:
                     res = [(existing[0], True)]
                 else:
                     res = [(dx, True)]
+            elif (not need_weight_grads and Model.use_conv_chains and getattr(op.node.layer, "fusable_activation", False)
+                  and self._audio_dgrad(plan, tape, i, producer, n_consumers, grads, g[0], need_input_grad)):
+                continue
             elif getattr(op.node.layer, "fusable_activation", False):
                 # the data-gradient kernel of a contraction can multiply its result by the saved
                 # activation derivative of the layer that produced its input (single consumer only)
@@ -667,6 +670,30 @@ class Model:
                     grads[id(t)] = r
         gi = grads.get(id(self.input))
         return gi[0] if gi is not None else None
+
+    def _audio_dgrad(self, plan, tape, i, producer, n_consumers, grads, dy, need_input_grad) -> bool:
+        """Backward sweeps without weight gradients: the data gradient of a block's first 3x3 convolution and of the
+        from-audio layer in front of it as one launch that never writes the 128-channel gradient between them.  True
+        when it ran (the from-audio step then finds no gradient waiting and is skipped)."""
+        from .layers import audio_dgrad_eligible, audio_dgrad_backward
+        op = plan[i]
+        j = producer.get(id(op.inputs[0]))
+        if j is None or n_consumers.get(id(op.inputs[0])) != 1 or isinstance(plan[j], _FusedOp):
+            return False
+        prod = plan[j]
+        if len(prod.inputs) != 1 or not audio_dgrad_eligible(op.node.layer, tape[i], prod.node.layer, tape[j]):
+            return False
+        t_in = prod.inputs[0]
+        if t_in is self.input and not need_input_grad:
+            return False
+        e = grads.get(id(t_in))
+        if e is not None and not e[1]:
+            return False                      # an aliased buffer is waiting there: the layer-by-layer path adds out of place
+        dxa = audio_dgrad_backward(op.node.layer, tape[i], prod.node.layer, tape[j], dy, e[0] if e is not None else None)
+        grads[id(t_in)] = (dxa, True)
+        tape[i] = None
+        tape[j] = None
+        return True
 
     # -- persistence (numpy archive; the reference's .h5 path needs h5py/Keras) --
     def get_weights_dict(self) -> Dict[str, np.ndarray]:

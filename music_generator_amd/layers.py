@@ -196,6 +196,37 @@ class _Contraction(Layer):
         return [(dx, True)]
 
 
+def audio_dgrad_eligible(conv, saved, audio_conv, audio_saved) -> bool:
+    """`conv` (the block's first 3x3 convolution, 128 -> 32, taped on the bf16 kernels) reads the output of `audio_conv`
+    (the from-audio layer, taped on the bf16 path with its output kept for the derivative): their two data gradients
+    can run as one launch (mgx_conv_dgrad_to_audio_bf16) when no weight gradient is wanted."""
+    if not (isinstance(saved, _BSaved) and isinstance(audio_saved, _BSaved) and isinstance(conv, Conv2D)):
+        return False
+    if saved.mode != "conv" or audio_saved.mode != "audio" or audio_saved.premultiplied:
+        return False
+    if audio_saved.dact is not None or audio_saved.yact is None or audio_saved.yact is not saved.x or not audio_saved.alpha > 0:
+        return False
+    if conv.cin != 128 or conv.filters != 32 or conv.kernel_size != (3, 3) or conv.strides != (1, 1) or conv.padding != "same":
+        return False
+    n, h, w, _ = saved.x.shape
+    return ops.conv_bf16_supported(conv._desc("d", n, h, w))
+
+
+def audio_dgrad_backward(conv, saved, audio_conv, audio_saved, dy, existing):
+    """Gradient of the audio (n, h, w, 2) float32 from dy, the gradient at `conv`'s output: new tensor, or `existing`
+    added to."""
+    x = saved.x
+    n, h, w, _ = x.shape
+    if saved.has_derivative() and not saved.premultiplied:
+        g = ops.mul_bf16(dy, saved.dact) if saved.dact is not None else ops.mul_dact_bf16(dy, saved.yact, saved.alpha)
+    else:
+        g = dy if dy.dtype == torch.bfloat16 else ops.cast_to_bf16(dy)
+    dxa = existing if existing is not None else K.empty(tuple(audio_saved.x.shape))
+    ops.conv_dgrad_to_audio_bf16(conv._desc("d", n, h, w), g, conv.kernel.value(), x, audio_saved.alpha,
+                                 audio_conv.kernel.value(), dxa, existing is not None)
+    return dxa
+
+
 def conv_pair_eligible(a, b, x) -> bool:
     """Layers a, b (each followed by a SoftRectifier) as one launch of the pair kernel: a is Conv2D(32, 3x3, same),
     b Conv2D(32, 3x3 or 2x2, same), both on 32 channels, bf16 input of at least 16 rows, bf16 precision on."""

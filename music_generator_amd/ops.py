@@ -663,6 +663,24 @@ def conv1x1_blend_bf16(d: ConvDesc, x, w, bias, old, alpha, y, act_alpha):
         PROFILER.stop("bconv_kernel<1,1,3>", _conv_flops(d), e0, _conv_bytes_bf16(d, 1, 2))
 
 
+def conv_dgrad_to_audio_bf16(d: ConvDesc, g, w, y128, act_alpha, audio_w, dx, accumulate):
+    """mgx_conv_dgrad_to_audio_bf16: data gradient of a 3x3 convolution 128 -> 32 (d: its data-gradient descriptor)
+    times the derivative recovered from y128 (the from-audio layer's stored output, act_alpha its alpha), contracted
+    with the from-audio kernel audio_w (2, 128) into dx (n, h, w, 2) float32."""
+    xe, ye, we = _conv_sizes(d)
+    if g.numel() != xe or y128.numel() != ye or w.numel() < we or audio_w.numel() != 256 or dx.numel() * 64 != ye:
+        raise MgxError("conv_dgrad_to_audio_bf16: operand sizes do not match the descriptor")
+    if dx.dtype != torch.float32 or g.dtype != torch.bfloat16 or y128.dtype != torch.bfloat16:
+        raise MgxError("conv_dgrad_to_audio_bf16: g, y128 bfloat16; dx float32")
+    d.accumulate = 0
+    d.act_alpha = float(act_alpha)
+    e0 = PROFILER.start() if PROFILER is not None else None
+    check(_lib().mgx_conv_dgrad_to_audio_bf16(C.byref(d), _pb(g), _p(w), _pb(y128), _p(audio_w), _p(dx),
+                                              1 if accumulate else 0, K.stream_ptr()), "mgx_conv_dgrad_to_audio_bf16")
+    if e0 is not None:
+        PROFILER.stop("bconv_kernel<3,3,6>", _conv_flops(d), e0, 2.0 * (xe + ye) + 4.0 * we + dx.numel() * 4)
+
+
 def conv1x1_blend_audio_bf16(d: ConvDesc, x, w, bias, audio, audio_w, audio_b, audio_alpha, alpha, y, act_alpha):
     """mgx_conv1x1_blend_audio_bf16: y = (1 - alpha) old + alpha act(conv1x1(x)) with old = the from-audio layer
     (kernel audio_w (2,128), bias audio_b, SoftRectifier audio_alpha) of the float32 audio (n, h, w, 2), re-computed in

@@ -167,6 +167,68 @@ def test_bf16_conv_forward_dgrad_wgrad(case):
     torch.cuda.synchronize()
 
 
+@pytest.mark.parametrize("n,h,w", [(2, 16, 150), (3, 18, 333), (1, 64, 1000), (2, 8, 75)])
+@pytest.mark.parametrize("accumulate", [False, True])
+def test_bf16_conv_dgrad_to_audio_equals_two_launches(n, h, w, accumulate):
+    """mgx_conv_dgrad_to_audio_bf16 (data gradient of the 3x3 convolution 128 -> 32 times the derivative recovered from
+    the from-audio layer's stored output, contracted with the from-audio kernel in registers) against
+    mgx_conv_gemm_bf16 (ymul) followed by mgx_pointwise_to2_bf16: the same bf16-rounded 128-channel values, another
+    order of the float32 sums over the 128 channels."""
+    M.clear_session()
+    conv = L.Conv2D(32, (3, 3), padding="same", kernel_initializer="he_normal")
+    conv(Input(shape=(h, w, 128)))
+    rng = np.random.default_rng(n * 100 + h + w)
+    alpha = 20000.0
+    g = _dev_b(rng.standard_normal((n, h, w, 32)))
+    y128 = _dev_b(np.tanh(rng.uniform(-3, 3, (n, h, w, 128))))
+    fa_w = _dev_f(rng.standard_normal((2, 128)).astype(np.float32))
+    dd = conv._desc("d", n, h, w)
+    g128 = torch.empty((n, h, w, 128), dtype=torch.bfloat16, device="cuda")
+    ops.conv_gemm_bf16(dd, g, conv.kernel.value(), None, g128, ymul=y128, act_alpha=alpha)
+    start = torch.from_numpy(rng.standard_normal((n, h, w, 2)).astype(np.float32)).cuda()
+    want = start.clone()
+    ops.pointwise_to2_bf16(g128, fa_w, want, n * h * w, accumulate)
+    got = start.clone() if accumulate else torch.full_like(start, float("nan"))
+    ops.conv_dgrad_to_audio_bf16(dd, g, conv.kernel.value(), y128, alpha, fa_w, got, accumulate)
+    torch.cuda.synchronize()
+    assert bool(torch.isfinite(got).all()), "positions left unwritten"
+    scale = float((want - (start if accumulate else 0)).abs().max())
+    assert float((got - want).abs().max()) <= 2e-6 * scale + 1e-6, (float((got - want).abs().max()), scale)
+
+
+def test_bf16_discriminator_input_gradient_with_and_without_fused_audio_dgrad(bf16_precision):
+    """The backward sweep of the generator step through a fade-in discriminator (no weight gradients, gradient of
+    the input wanted) with the 3x3 + from-audio data gradients as one launch per grown block, against the
+    layer-by-layer sweep."""
+    from music_generator_amd.graph import Model
+    d, g, comp, W = _build(4)
+    model = d[3][1]
+    for layer in model.layers:
+        if isinstance(layer, M.WeightedSum):
+            M.backend.set_value(layer.alpha, 0.37)
+    real, _ = R.synthetic_inputs(3, 4, seed=5)
+    x = torch.from_numpy(real).cuda()
+    calls = []
+    orig = ops.conv_dgrad_to_audio_bf16
+    ops.conv_dgrad_to_audio_bf16 = lambda *a, **k: (calls.append(1), orig(*a, **k))[1]
+    chains = Model.use_conv_chains
+    try:
+        outs = []
+        for fused in (True, False):
+            Model.use_conv_chains = fused
+            y, tape = model.forward(x, save=True)
+            dy = torch.ones_like(y)
+            outs.append(model.backward(tape, dy, need_input_grad=True, need_weight_grads=False).clone())
+            if fused:
+                n_fused = len(calls)
+        assert n_fused >= 1 and len(calls) == n_fused
+    finally:
+        Model.use_conv_chains = chains
+        ops.conv_dgrad_to_audio_bf16 = orig
+    a, b = outs
+    assert float((a - b).norm()) <= 1e-5 * float(b.norm()), (float((a - b).norm()), float(b.norm()))
+
+
 def test_bf16_from_audio_conv():
     """1x1 convolution 2 float32 channels -> 128 bf16 channels, its gradients."""
     rng = np.random.default_rng(5)
