@@ -387,7 +387,9 @@ class Model:
     # 2x2}, {3x3, 3x3}, {3x3, 2x2}: the groups of a discriminator block) go through the row-streaming chain kernel
     # (mgx_conv_chain_bf16; bit-identical results, the inner layers' outputs never reach HBM).  The same switch
     # covers the other launch-saving rules of tape-free passes: the from-audio + 3x3 kernel (bf16) and the fade-in
-    # blend in the epilogue of a block's last 1x1 convolution (float32 and bf16).
+    # blend in the epilogue of a block's last 1x1 convolution (float32 and bf16; in bf16 with the blend's other input,
+    # the old stage's from-audio layer, re-computed there), and the one rule of backward sweeps without weight
+    # gradients: the data gradients of a block's first 3x3 convolution and of the from-audio layer as one launch.
     use_conv_chains = os.environ.get("MGX_CONV_CHAINS", "1") != "0"      # MGX_CONV_CHAINS=0: layer by layer (measurements)
     # True: the same groups of a TAPED bf16 pass run as one launch too (mgx_conv_chain_bf16_taped): every layer's
     # output is written for the backward, but the inner ones are not read back (256 instead of 384 bytes a position
